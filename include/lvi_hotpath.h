@@ -1,0 +1,300 @@
+/*
+ * lvi_hotpath.h — C-ABI of the MI355X-native hot path of
+ * valentinomario/LiDAR-Visual-Inertial-SLAM.
+ *
+ * The reference has no FFI / plugin interface of its own: the algorithms are
+ * member functions of ROS 2 node classes.  This header is the seam a maintainer
+ * binds instead of those member functions; every entry point names the
+ * reference call site it replaces (paths relative to the reference tree,
+ * lidar_odometry/src/… and feature_tracker/src/…).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch/ROS types cross the ABI.
+ *   - every function returns an int32 status: 0 OK, <0 hard error,
+ *     >0 soft outcome mirrored from the reference (it warned / skipped / returned false).
+ *   - the caller owns every host buffer; the library owns device memory behind
+ *     the opaque handles.  No exception crosses the ABI.
+ *   - one handle per node; calls on one handle are serialised by the caller
+ *     (SingleThreadedExecutor featureExtraction.cpp:273, lock_guard
+ *     mapOptimization.cpp:309).  Handles on different GPUs are independent.
+ *   - two libraries export these symbols: liblvi_hip.so (the product, HIP/gfx950)
+ *     and oracle/liblvi_oracle.so (CPU restatement, test infrastructure only).
+ *     Entry points marked [hip only] exist only in the product library.
+ */
+#ifndef LVI_HOTPATH_H
+#define LVI_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVI_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------- */
+#define LVI_OK                        0
+#define LVI_ERR_INVALID_ARG          -1
+#define LVI_ERR_NO_DEVICE            -2   /* no HIP device / HIP runtime failure at create */
+#define LVI_ERR_HIP                  -3   /* a HIP call failed; see lvi_last_error() */
+#define LVI_ERR_CAPACITY             -4   /* input exceeds the capacity given at create */
+#define LVI_ERR_STATE                -5   /* stage called before its producer stage */
+#define LVI_ERR_UNSUPPORTED          -6
+/* soft outcomes (reference behaviour, not failures) */
+#define LVI_TOO_FEW_FEATURES          1   /* mapOptimization.cpp:1320,1341  "Not enough features!" */
+#define LVI_TOO_FEW_CORRESPONDENCES   2   /* mapOptimization.cpp:1210  LMOptimization returned false on <50 rows */
+#define LVI_NO_MAP                    3   /* mapOptimization.cpp:1317  no key poses yet → no scan matching */
+
+/* ---- plain data ---------------------------------------------------------- */
+
+/* pcl::PointXYZI as used on the path (utility.h:64).  PCL stores 32 B/point; only
+ * these 16 B carry information and this is the layout used in HBM. */
+typedef struct lvi_pt { float x, y, z, intensity; } lvi_pt;
+
+/* livox_ros_driver2/CustomPoint (imageProjection.cpp:17-29, 249-258). */
+typedef struct lvi_livox_pt {
+    float    x, y, z;
+    uint8_t  reflectivity;
+    uint8_t  tag;
+    uint8_t  line;
+    uint8_t  _pad;
+    uint32_t offset_time;     /* ns from the scan header stamp */
+} lvi_livox_pt;
+
+/* ParamServer fields read on the path (utility.h:156-313, params_lidar.yaml). */
+typedef struct lvi_lidar_params {
+    int32_t N_SCAN;                     /* yaml 4 */
+    int32_t Horizon_SCAN;               /* yaml 6000 */
+    int32_t downsampleRate;             /* yaml 1 */
+    float   lidarMinRange;              /* yaml 1.0 */
+    float   lidarMaxRange;              /* yaml 100.0 */
+    float   edgeThreshold;              /* yaml 1.0 */
+    float   surfThreshold;              /* yaml 0.1 */
+    int32_t edgeFeatureMinValidNum;     /* yaml 10 */
+    int32_t surfFeatureMinValidNum;     /* yaml 100 */
+    float   odometrySurfLeafSize;       /* yaml 0.4 */
+    float   mappingCornerLeafSize;      /* yaml 0.2 */
+    float   mappingSurfLeafSize;        /* yaml 0.4 */
+    float   z_tollerance;               /* yaml 1000 */
+    float   rotation_tollerance;        /* yaml 1000 */
+    float   imuRPYWeight;               /* yaml 0.01 */
+    int32_t numberOfCores;              /* yaml 8; OpenMP threads of the CPU oracle only */
+    /* scan2MapOptimization loop (mapOptimization.cpp:1325-1337) */
+    int32_t icp_max_iters;              /* 20 */
+    int32_t icp_disable_break;          /* 0 = reference semantics; 1 = run exactly icp_max_iters (throughput runs) */
+    /* capacities (sizes of the device arenas) */
+    int32_t max_raw_points;             /* per scan, Msg.point_num upper bound */
+    int32_t max_map_points;             /* raw local-map points, corner + surf each */
+} lvi_lidar_params;
+
+/* CloudInfo.msg:4-8 arrays + cloud_deskewed, as plain caller-owned arrays.
+ * capacity = number of elements the three per-point arrays can hold. */
+typedef struct lvi_scan_info {
+    int32_t  capacity;
+    int32_t  n;                  /* out: extractedCloud->size() */
+    int32_t *start_ring_index;   /* [N_SCAN] */
+    int32_t *end_ring_index;     /* [N_SCAN] */
+    int32_t *point_col_ind;      /* [capacity] */
+    float   *point_range;        /* [capacity] */
+    lvi_pt  *cloud_deskewed;     /* [capacity] */
+} lvi_scan_info;
+
+/* caller-owned point array with capacity; n is written by the library */
+typedef struct lvi_cloud {
+    int32_t capacity;
+    int32_t n;
+    lvi_pt *pts;
+} lvi_cloud;
+
+/* CloudInfo fields consumed by transformUpdate (mapOptimization.cpp:1345-1368) */
+typedef struct lvi_imu_hint {
+    int32_t imu_available;
+    float   imu_roll_init, imu_pitch_init, imu_yaw_init;
+} lvi_imu_hint;
+
+#define LVI_ICP_MAX_ITERS 64
+typedef struct lvi_icp_result {
+    int32_t status;              /* LVI_OK or a soft outcome */
+    int32_t iters;               /* iterations executed (LMOptimization calls) */
+    int32_t converged;           /* LMOptimization returned true */
+    int32_t degenerate;          /* isDegenerate (mapOptimization.cpp:1271-1283) */
+    int32_t n_corner_ds, n_surf_ds;          /* laserCloud{Corner,Surf}LastDSNum */
+    int32_t n_sel[LVI_ICP_MAX_ITERS];        /* laserCloudSelNum per iteration */
+    float   pose[6];             /* transformTobeMapped after transformUpdate: roll,pitch,yaw,x,y,z */
+} lvi_icp_result;
+
+/* the 32-byte record gathered across GPUs (one per scan) */
+typedef struct lvi_pose_record {
+    float   pose[6];
+    int32_t status;
+    int32_t iters;
+} lvi_pose_record;
+
+typedef struct lvi_lidar lvi_lidar;        /* opaque */
+
+/* ---- library ------------------------------------------------------------- */
+int32_t     lvi_abi_version(void);
+const char *lvi_backend(void);             /* "hip-gfx950" or "cpu-oracle" */
+const char *lvi_last_error(void);          /* thread-local text of the last hard error */
+
+/* ---- lidar handle -------------------------------------------------------- */
+void    lvi_lidar_params_default(lvi_lidar_params *p);      /* values of params_lidar.yaml */
+int32_t lvi_lidar_create(const lvi_lidar_params *p, int32_t device, lvi_lidar **out);
+void    lvi_lidar_destroy(lvi_lidar *h);
+int32_t lvi_lidar_sync(lvi_lidar *h);                       /* wait for the handle's stream */
+
+/* ---- one-call entry points with host buffers (a maintainer's drop-in seams) */
+
+/* a-0  ImageProjection::moveFromCustomMsg + projectPointCloud + cloudExtraction
+ *      (imageProjection.cpp:239-260, 570-647), imu_available == false (no deskew).
+ *      n_raw = Msg.point_num; the final point is dropped as the reference does (:249). */
+int32_t lvi_organize_scan(lvi_lidar *h, const lvi_livox_pt *pts, int32_t n_raw, lvi_scan_info *out);
+
+/* a-1..a-4  FeatureExtraction::laserCloudInfoHandler (featureExtraction.cpp:72-85):
+ *      calculateSmoothness, markOccludedPoints, extractFeatures (incl. per-ring VoxelGrid). */
+int32_t lvi_extract_features(lvi_lidar *h, const lvi_scan_info *in, lvi_cloud *corner, lvi_cloud *surf);
+
+/* a-4  pcl::VoxelGrid<PointXYZI>::filter with setLeafSize(leaf,leaf,leaf)
+ *      (featureExtraction.cpp:61,240-241; mapOptimization.cpp:247-250,959-964,991-997). */
+int32_t lvi_voxel_downsample(lvi_lidar *h, const lvi_pt *in, int32_t n, float leaf, lvi_pt *out, int32_t out_capacity, int32_t *n_out);
+
+/* a-4 + a-6  extractCloud's two VoxelGrid calls over the fused local map and the two
+ *      KdTreeFLANN::setInputCloud calls (mapOptimization.cpp:958-965, 1322-1323).
+ *      Inputs are laserCloud{Corner,Surf}FromMap (already in the map frame). */
+int32_t lvi_map_set(lvi_lidar *h, const lvi_pt *corner_raw, int32_t nc, const lvi_pt *surf_raw, int32_t ns);
+
+/* a-4(scan DS) + a-5..a-10  downsampleCurrentScan + scan2MapOptimization
+ *      (mapOptimization.cpp:987-999, 1315-1375).  pose = transformTobeMapped
+ *      [roll,pitch,yaw,x,y,z], in: initial guess, out: result. */
+int32_t lvi_scan_to_map(lvi_lidar *h, const lvi_pt *corner, int32_t nc, const lvi_pt *surf, int32_t ns,
+                        const lvi_imu_hint *imu, float pose[6], lvi_icp_result *out);
+
+/* a-5  mapOptimization::transformPointCloud (mapOptimization.cpp:347-385) with
+ *      pcl::getTransformation(x,y,z,roll,pitch,yaw); pose6 = [roll,pitch,yaw,x,y,z]. */
+int32_t lvi_transform_cloud(lvi_lidar *h, const lvi_pt *in, int32_t n, const float pose6[6], lvi_pt *out);
+
+/* ---- staged, device-resident form of the same path -----------------------
+ * upload → run stages on the handle's stream → fetch.  Used by the replay
+ * harness and bench so that inputs are resident in HBM when timing starts. */
+int32_t lvi_scan_upload(lvi_lidar *h, const lvi_livox_pt *pts, int32_t n_raw);   /* H2D only */
+int32_t lvi_scan_organize(lvi_lidar *h);                                         /* a-0 */
+int32_t lvi_scan_extract(lvi_lidar *h);                                          /* a-1..a-4 */
+int32_t lvi_scan_downsample(lvi_lidar *h);                                       /* downsampleCurrentScan :987-999 */
+int32_t lvi_map_upload(lvi_lidar *h, const lvi_pt *corner_raw, int32_t nc, const lvi_pt *surf_raw, int32_t ns);
+int32_t lvi_map_build(lvi_lidar *h);                                             /* extractCloud DS + index build */
+int32_t lvi_scan_match(lvi_lidar *h, const lvi_imu_hint *imu, float pose[6], lvi_icp_result *out);
+/* [hip only] enqueue scan matching, write the 32-B pose record to device memory
+ * (d_record: device pointer, e.g. a slot of the buffer RCCL all-gathers); no host sync. */
+int32_t lvi_scan_match_async(lvi_lidar *h, const float pose_init[6], void *d_record);
+
+/* fetch current stage outputs (host buffers) */
+int32_t lvi_get_scan_info(lvi_lidar *h, lvi_scan_info *out);
+int32_t lvi_get_features(lvi_lidar *h, lvi_cloud *corner, lvi_cloud *surf);       /* cornerCloud, surfaceCloud */
+int32_t lvi_get_scan_ds(lvi_lidar *h, lvi_cloud *corner_ds, lvi_cloud *surf_ds);  /* laserCloud{Corner,Surf}LastDS */
+int32_t lvi_get_map_ds(lvi_lidar *h, lvi_cloud *corner_ds, lvi_cloud *surf_ds);   /* laserCloud{Corner,Surf}FromMapDS */
+int32_t lvi_get_counts(lvi_lidar *h, int32_t counts[8]);
+/* counts: [0] n extracted, [1] corners, [2] surf (after per-ring DS), [3] corner DS, [4] surf DS,
+ *         [5] map corner DS, [6] map surf DS, [7] reserved */
+
+/* ---- inspection of intermediates (parity tests) ---------------------------- */
+enum {
+    LVI_DBG_CURVATURE      = 1,   /* f32[n]   cloudCurvature            (featureExtraction.cpp:103) */
+    LVI_DBG_PICKED_OCCL    = 2,   /* i32[n]   cloudNeighborPicked after markOccludedPoints (:113-148) */
+    LVI_DBG_LABEL          = 3,   /* i32[n]   cloudLabel after extractFeatures: 1 corner, -1 surf-picked, 0 */
+    LVI_DBG_PICKED_FINAL   = 4,   /* i32[n]   cloudNeighborPicked after extractFeatures */
+    LVI_DBG_CORNER_INDEX   = 5,   /* i32[C]   index into extractedCloud of every corner, in output order */
+    LVI_DBG_VOXEL_KEYS     = 6,   /* i32[P]   per-input-point voxel idx of the last lvi_voxel_downsample call */
+    LVI_DBG_VOXEL_CELLS    = 7,   /* i32[V]   distinct idx, ascending = output order, same call */
+    LVI_DBG_VOXEL_COUNTS   = 8,   /* i32[V]   points per output voxel, same call */
+    LVI_DBG_ICP_JTJ        = 9,   /* f32[iters*27] 21 upper-triangular AtA + 6 AtB per iteration */
+    LVI_DBG_ICP_POSE_TRACE = 10   /* f32[(iters+1)*6] transformTobeMapped before iteration k (and after the last) */
+};
+int32_t lvi_debug_get(lvi_lidar *h, int32_t what, void *dst, int64_t capacity_bytes, int64_t *n_bytes);
+
+/* a-6  5-NN of arbitrary query points against the current DS map (which: 0 corner, 1 surf).
+ *      idx: [nq*5] indices into laserCloud*FromMapDS; sqd: [nq*5] squared distances, ascending.
+ *      For a query whose 5th neighbour is not closer than 1 m (rejected at
+ *      mapOptimization.cpp:1025,1121) idx is -1 and sqd is +inf from the first slot that is not < 1.0. */
+int32_t lvi_debug_knn(lvi_lidar *h, int32_t which, const lvi_pt *queries, int32_t nq, int32_t *idx, float *sqd);
+
+/* a-7/a-8  one pass of cornerOptimization / surfOptimization at a given pose over the
+ *      current DS scan: coeff[nq] (coeffSel entry), flag[nq] (laserCloudOri*Flag). */
+int32_t lvi_debug_residuals(lvi_lidar *h, int32_t which, const float pose[6], lvi_pt *coeff, uint8_t *flag, int32_t capacity, int32_t *n);
+
+/* ---- kernel timing (HIP events on the handle's stream) ---------------------
+ * [hip only]  enable, run stages, then read accumulated per-kernel time. */
+typedef struct lvi_kernel_stat {
+    char     name[48];
+    int64_t  launches;
+    double   total_ms;
+    double   bytes_alg;          /* algorithmic bytes summed over launches (DESIGN.md per-kernel formulas) */
+} lvi_kernel_stat;
+int32_t lvi_prof_enable(lvi_lidar *h, int32_t on);
+int32_t lvi_prof_reset(lvi_lidar *h);
+int32_t lvi_prof_read(lvi_lidar *h, lvi_kernel_stat *stats, int32_t capacity, int32_t *n);
+
+/* =========================================================================== */
+/* feature_tracker                                                             */
+/* =========================================================================== */
+
+/* parameters.cpp:53-110 globals read on the path + cv:: defaults fixed by the call
+ * sites feature_tracker.cpp:113 and :166. */
+typedef struct lvi_tracker_params {
+    int32_t max_width, max_height;   /* capacity; yaml 1024x576, benchmark 1280x720 */
+    int32_t max_cnt;                 /* MAX_CNT   yaml 150 */
+    double  min_dist;                /* MIN_DIST  yaml 20 (int in the reference, passed as double minDistance) */
+    int32_t lk_win;                  /* 21  (cv::Size(21,21)) */
+    int32_t lk_max_level;            /* 3   → 4 pyramid levels */
+    int32_t lk_max_iters;            /* 30  (TermCriteria default) */
+    double  lk_eps;                  /* 0.01 (TermCriteria::epsilon, double) */
+    float   lk_min_eig_threshold;    /* 1e-4 */
+    double  gftt_quality;            /* 0.01 (double qualityLevel) */
+    int32_t max_features;            /* capacity of the per-frame point arrays */
+} lvi_tracker_params;
+
+typedef struct lvi_tracker lvi_tracker;    /* opaque */
+
+void    lvi_tracker_params_default(lvi_tracker_params *p);
+int32_t lvi_tracker_create(const lvi_tracker_params *p, int32_t device, lvi_tracker **out);
+void    lvi_tracker_destroy(lvi_tracker *t);
+int32_t lvi_tracker_sync(lvi_tracker *t);
+
+/* a-11  cv::calcOpticalFlowPyrLK(cur_img, forw_img, cur_pts, forw_pts, status, err,
+ *       cv::Size(21,21), 3)  (feature_tracker.cpp:113). */
+int32_t lvi_lk_track(lvi_tracker *t, const uint8_t *prev, const uint8_t *next, int32_t w, int32_t h, int32_t stride,
+                     const float *prev_xy, int32_t n, float *next_xy, uint8_t *status, float *err);
+
+/* a-12  cv::goodFeaturesToTrack(forw_img, n_pts, max_corners, quality, min_dist, mask)
+ *       (feature_tracker.cpp:166).  mask may be NULL (all 255). */
+int32_t lvi_good_features(lvi_tracker *t, const uint8_t *img, const uint8_t *mask, int32_t w, int32_t h, int32_t stride,
+                          int32_t max_corners, double quality, double min_dist, float *xy, int32_t xy_capacity, int32_t *n_out);
+
+/* staged form mirroring FeatureTracker::readImage's image rotation
+ * (feature_tracker.cpp:94-101, 200-204): push makes the new image "forw"
+ * (its pyramid is built once and kept resident), the previous forw becomes "cur". */
+int32_t lvi_tracker_push_image(lvi_tracker *t, const uint8_t *img, int32_t w, int32_t h, int32_t stride);
+int32_t lvi_tracker_set_points(lvi_tracker *t, const float *cur_xy, int32_t n);                   /* H2D cur_pts */
+int32_t lvi_tracker_run_lk(lvi_tracker *t);                                                        /* cur → forw, device-resident */
+int32_t lvi_tracker_get_lk(lvi_tracker *t, float *forw_xy, uint8_t *status, float *err, int32_t capacity, int32_t *n);
+int32_t lvi_tracker_set_mask(lvi_tracker *t, const uint8_t *mask, int32_t w, int32_t h, int32_t stride); /* NULL → all 255 */
+int32_t lvi_tracker_run_gftt(lvi_tracker *t, int32_t max_corners);                                 /* on forw */
+int32_t lvi_tracker_get_gftt(lvi_tracker *t, float *xy, int32_t capacity, int32_t *n);
+
+enum {
+    LVI_TDBG_PYRAMID_L1 = 1,   /* u8 level-1 image of forw (pyrDown) */
+    LVI_TDBG_PYRAMID_L2 = 2,
+    LVI_TDBG_PYRAMID_L3 = 3,
+    LVI_TDBG_MINEIG     = 4,   /* f32[h*w] cornerMinEigenVal map of forw */
+    LVI_TDBG_GFTT_NCAND = 5    /* i32[1]  number of local-maximum candidates before the distance filter */
+};
+int32_t lvi_tracker_debug_get(lvi_tracker *t, int32_t what, void *dst, int64_t capacity_bytes, int64_t *n_bytes);
+
+int32_t lvi_tracker_prof_enable(lvi_tracker *t, int32_t on);
+int32_t lvi_tracker_prof_reset(lvi_tracker *t);
+int32_t lvi_tracker_prof_read(lvi_tracker *t, lvi_kernel_stat *stats, int32_t capacity, int32_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVI_HOTPATH_H */

@@ -1,0 +1,131 @@
+"""Python handle over the feature_tracker half of the C-ABI (include/lvi_hotpath.h):
+cv::calcOpticalFlowPyrLK (feature_tracker.cpp:113) and cv::goodFeaturesToTrack (:166)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi as A
+
+
+def default_tracker_params(lib, **overrides):
+    p = A.TrackerParams()
+    lib.dll.lvi_tracker_params_default(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(f"lvi_tracker_params has no field {k}")
+        setattr(p, k, v)
+    return p
+
+
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+class TrackerHotpath:
+    def __init__(self, lib, params=None, device=0, **overrides):
+        self.lib = lib
+        self.params = params if params is not None else default_tracker_params(lib, **overrides)
+        self._t = C.c_void_p()
+        lib.check(lib.dll.lvi_tracker_create(C.byref(self.params), int(device), C.byref(self._t)), "lvi_tracker_create")
+
+    def close(self):
+        if self._t:
+            self.lib.dll.lvi_tracker_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- one-call seams ---------------------------------------------------
+    def lk_track(self, prev, nxt, prev_xy):
+        prev, nxt = _img(prev), _img(nxt)
+        xy = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+        n = len(xy)
+        out = np.zeros((max(n, 1), 2), np.float32)
+        status = np.zeros(max(n, 1), np.uint8)
+        err = np.zeros(max(n, 1), np.float32)
+        h, w = prev.shape
+        self.lib.check(self.lib.dll.lvi_lk_track(self._t, A._ptr(prev), A._ptr(nxt), w, h, prev.strides[0], A._ptr(xy), n,
+                                                 A._ptr(out), A._ptr(status), A._ptr(err)), "lvi_lk_track")
+        return out[:n], status[:n], err[:n]
+
+    def good_features(self, img, max_corners, quality=0.01, min_dist=20.0, mask=None):
+        img = _img(img)
+        h, w = img.shape
+        m = _img(mask) if mask is not None else None
+        cap = int(self.params.max_features)
+        xy = np.zeros((cap, 2), np.float32)
+        n = C.c_int32(0)
+        self.lib.check(self.lib.dll.lvi_good_features(self._t, A._ptr(img), A._ptr(m) if m is not None else None, w, h, img.strides[0],
+                                                      int(max_corners), float(quality), float(min_dist), A._ptr(xy), cap, C.byref(n)),
+                       "lvi_good_features")
+        return xy[:n.value].copy()
+
+    # ---- staged form --------------------------------------------------------
+    def push_image(self, img):
+        img = _img(img)
+        h, w = img.shape
+        self.lib.check(self.lib.dll.lvi_tracker_push_image(self._t, A._ptr(img), w, h, img.strides[0]), "lvi_tracker_push_image")
+
+    def set_points(self, xy):
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        self.lib.check(self.lib.dll.lvi_tracker_set_points(self._t, A._ptr(xy), len(xy)), "lvi_tracker_set_points")
+
+    def run_lk(self):
+        self.lib.check(self.lib.dll.lvi_tracker_run_lk(self._t), "lvi_tracker_run_lk")
+
+    def get_lk(self):
+        cap = int(self.params.max_features)
+        xy = np.zeros((cap, 2), np.float32)
+        st = np.zeros(cap, np.uint8)
+        err = np.zeros(cap, np.float32)
+        n = C.c_int32(0)
+        self.lib.check(self.lib.dll.lvi_tracker_get_lk(self._t, A._ptr(xy), A._ptr(st), A._ptr(err), cap, C.byref(n)), "lvi_tracker_get_lk")
+        return xy[:n.value].copy(), st[:n.value].copy(), err[:n.value].copy()
+
+    def set_mask(self, mask):
+        if mask is None:
+            self.lib.check(self.lib.dll.lvi_tracker_set_mask(self._t, None, 0, 0, 0), "lvi_tracker_set_mask")
+            return
+        m = _img(mask)
+        h, w = m.shape
+        self.lib.check(self.lib.dll.lvi_tracker_set_mask(self._t, A._ptr(m), w, h, m.strides[0]), "lvi_tracker_set_mask")
+
+    def run_gftt(self, max_corners):
+        self.lib.check(self.lib.dll.lvi_tracker_run_gftt(self._t, int(max_corners)), "lvi_tracker_run_gftt")
+
+    def get_gftt(self):
+        cap = int(self.params.max_features)
+        xy = np.zeros((cap, 2), np.float32)
+        n = C.c_int32(0)
+        self.lib.check(self.lib.dll.lvi_tracker_get_gftt(self._t, A._ptr(xy), cap, C.byref(n)), "lvi_tracker_get_gftt")
+        return xy[:n.value].copy()
+
+    def sync(self):
+        self.lib.check(self.lib.dll.lvi_tracker_sync(self._t), "lvi_tracker_sync")
+
+    def debug_get(self, what, dtype):
+        nb = C.c_int64(0)
+        self.lib.check(self.lib.dll.lvi_tracker_debug_get(self._t, int(what), None, 0, C.byref(nb)), "lvi_tracker_debug_get(size)")
+        out = np.zeros(nb.value // np.dtype(dtype).itemsize, dtype)
+        if out.size:
+            self.lib.check(self.lib.dll.lvi_tracker_debug_get(self._t, int(what), A._ptr(out), out.nbytes, C.byref(nb)), "lvi_tracker_debug_get")
+        return out
+
+    def prof_enable(self, on=True):
+        self.lib.check(self.lib.dll.lvi_tracker_prof_enable(self._t, 1 if on else 0), "lvi_tracker_prof_enable")
+
+    def prof_reset(self):
+        self.lib.check(self.lib.dll.lvi_tracker_prof_reset(self._t), "lvi_tracker_prof_reset")
+
+    def prof_read(self):
+        stats = (A.KernelStat * 128)()
+        n = C.c_int32(0)
+        self.lib.check(self.lib.dll.lvi_tracker_prof_read(self._t, stats, 128, C.byref(n)), "lvi_tracker_prof_read")
+        return [dict(name=stats[i].name.decode(), launches=stats[i].launches, total_ms=stats[i].total_ms, bytes_alg=stats[i].bytes_alg)
+                for i in range(n.value)]
