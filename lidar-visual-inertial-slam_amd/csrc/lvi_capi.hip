@@ -1,0 +1,557 @@
+// C-ABI of the lidar half (include/lvi_hotpath.h) over the HIP stages.  Host-side only:
+// argument checks, H2D/D2H, stage ordering, error mapping.  No CPU fallback exists: every
+// compute entry point enqueues HIP kernels or fails.
+#include <algorithm>
+#include <cmath>
+
+#include "lvi_lidar.hpp"
+
+namespace lvi {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+// ---- Profiler ---------------------------------------------------------------------------------
+int Profiler::name_id(const char* n)
+{
+    for (size_t i = 0; i < names.size(); i++) if (names[i] == n) return (int)i;
+    names.emplace_back(n); launches.push_back(0); total_ms.push_back(0.0); bytes.push_back(0.0);
+    return (int)names.size() - 1;
+}
+hipEvent_t Profiler::get_event()
+{
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void Profiler::collect()
+{
+    for (auto& r : recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { launches[r.name_id]++; total_ms[r.name_id] += ms; bytes[r.name_id] += r.bytes; }
+        pool.push_back(r.a); pool.push_back(r.b);
+    }
+    recs.clear();
+}
+void Profiler::reset()
+{
+    collect();
+    std::fill(launches.begin(), launches.end(), 0); std::fill(total_ms.begin(), total_ms.end(), 0.0); std::fill(bytes.begin(), bytes.end(), 0.0);
+}
+Profiler::~Profiler()
+{
+    for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : pool) (void)hipEventDestroy(e);
+}
+
+// defined in lvi_voxel.hip
+void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector<int32_t>& keys, std::vector<int32_t>& cells, std::vector<int32_t>& counts);
+
+}  // namespace lvi
+
+using namespace lvi;
+
+struct lvi_lidar {
+    LidarDev d;
+    std::vector<int32_t> vkeys, vcells, vcounts;    // debug of the last lvi_voxel_downsample
+    bool have_icp_host = false;
+};
+
+namespace {
+
+int32_t fail(int32_t code, const std::string& msg) { set_error(msg); return code; }
+
+template <class F>
+int32_t guarded(lvi_lidar* h, F&& f)
+{
+    try {
+        if (h) LVI_HIP(hipSetDevice(h->d.device));
+        return f();
+    } catch (const HipError& e) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", e.what, hipGetErrorString(e.e), e.file, e.line);
+        return fail(LVI_ERR_HIP, buf);
+    } catch (const std::exception& e) {
+        return fail(LVI_ERR_HIP, e.what());
+    }
+}
+
+void sync(LidarDev& d) { LVI_HIP(hipStreamSynchronize(d.ctx.stream)); }
+
+template <class T>
+void d2h(LidarDev& d, T* dst, const T* src, size_t n)
+{
+    if (n) LVI_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, d.ctx.stream));
+}
+template <class T>
+void h2d(LidarDev& d, T* dst, const T* src, size_t n)
+{
+    if (n) LVI_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, d.ctx.stream));
+}
+
+int read_int(LidarDev& d, const int* p)
+{
+    int v = 0;
+    d2h(d, &v, p, 1);
+    sync(d);
+    return v;
+}
+
+int32_t check_dev_status(LidarDev& d)
+{
+    const int st = read_int(d, d.d_status);
+    if (st & DEV_ERR_SECTOR_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "a ring sector exceeds FEAT_SEG_CAP points (Horizon_SCAN too large for the LDS-resident sector kernel)");
+    if (st & DEV_ERR_GRID_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "local map extent too large for the KNN grid");
+    return LVI_OK;
+}
+
+int32_t fetch_cloud(LidarDev& d, const lvi_pt* src, int n, lvi_cloud* dst)
+{
+    if (!dst) return LVI_OK;
+    dst->n = n;
+    if (dst->capacity < n || (!dst->pts && n > 0)) return fail(LVI_ERR_CAPACITY, "cloud capacity too small");
+    d2h(d, dst->pts, src, (size_t)n);
+    sync(d);
+    return LVI_OK;
+}
+
+struct Counts { int n, ncorner, nsurf, ncds, nsds, mcds, msds; };
+Counts read_counts(LidarDev& d)
+{
+    Counts c{};
+    int a = 0, b = 0, ring[MAX_N_SCAN + 1] = {0}, sc[3] = {0}, mp[3] = {0};
+    if (d.have_org) d2h(d, &a, d.d_n, 1);
+    if (d.have_feat) { d2h(d, &b, d.d_ncorner, 1); d2h(d, ring, d.voxRing.d_nout, (size_t)d.P.N_SCAN + 1); }
+    if (d.have_ds) d2h(d, sc, d.voxScan.d_nout, 3);
+    if (d.have_map) d2h(d, mp, d.voxMap.d_nout, 3);
+    sync(d);
+    c.n = a; c.ncorner = b; c.nsurf = ring[d.P.N_SCAN]; c.ncds = sc[0]; c.nsds = sc[1]; c.mcds = mp[0]; c.msds = mp[1];
+    return c;
+}
+
+template <class T, class U>
+int32_t dbg_out(const std::vector<T>& v, U, void* dst, int64_t cap, int64_t* n_bytes)
+{
+    const int64_t bytes = (int64_t)(v.size() * sizeof(T));
+    if (n_bytes) *n_bytes = bytes;
+    if (!dst) return LVI_OK;
+    if (cap < bytes) return fail(LVI_ERR_CAPACITY, "debug buffer too small");
+    if (bytes) memcpy(dst, v.data(), (size_t)bytes);
+    return LVI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t lvi_abi_version(void) { return LVI_ABI_VERSION; }
+const char* lvi_backend(void) { return "hip-gfx950"; }
+const char* lvi_last_error(void) { return lvi::g_err.c_str(); }
+
+void lvi_lidar_params_default(lvi_lidar_params* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->N_SCAN = 4; p->Horizon_SCAN = 6000; p->downsampleRate = 1;
+    p->lidarMinRange = 1.0f; p->lidarMaxRange = 100.0f;
+    p->edgeThreshold = 1.0f; p->surfThreshold = 0.1f;
+    p->edgeFeatureMinValidNum = 10; p->surfFeatureMinValidNum = 100;
+    p->odometrySurfLeafSize = 0.4f; p->mappingCornerLeafSize = 0.2f; p->mappingSurfLeafSize = 0.4f;
+    p->z_tollerance = 1000.0f; p->rotation_tollerance = 1000.0f; p->imuRPYWeight = 0.01f;
+    p->numberOfCores = 8;
+    p->icp_max_iters = 20; p->icp_disable_break = 0;
+    p->max_raw_points = 131072; p->max_map_points = 1 << 20;
+}
+
+int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** out)
+{
+    if (!p || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (p->N_SCAN <= 0 || p->N_SCAN > MAX_N_SCAN || p->Horizon_SCAN <= 0 || p->downsampleRate <= 0)
+        return fail(LVI_ERR_INVALID_ARG, "bad scan geometry (N_SCAN must be 1..32)");
+    if (p->icp_max_iters < 0) return fail(LVI_ERR_INVALID_ARG, "icp_max_iters < 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LVI_ERR_NO_DEVICE, "no HIP device: the HIP path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(LVI_ERR_NO_DEVICE, "device index out of range");
+    lvi_lidar* h = new lvi_lidar();
+    h->d.P = *p; h->d.device = device;
+    int32_t st = guarded(h, [&]() -> int32_t {
+        LVI_HIP(hipStreamCreateWithFlags(&h->d.ctx.stream, hipStreamNonBlocking));
+        h->d.ctx.prof = &h->d.prof;
+        lidar_allocate(h->d);
+        return LVI_OK;
+    });
+    if (st != LVI_OK) { lvi_lidar_destroy(h); return st; }
+    *out = h;
+    return LVI_OK;
+}
+
+void lvi_lidar_destroy(lvi_lidar* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->d.device);
+    if (h->d.ctx.stream) { (void)hipStreamSynchronize(h->d.ctx.stream); }
+    h->d.prof.collect();
+    h->d.arena.release();
+    if (h->d.h_icp) (void)hipHostFree(h->d.h_icp);
+    if (h->d.ctx.stream) (void)hipStreamDestroy(h->d.ctx.stream);
+    delete h;
+}
+
+int32_t lvi_lidar_sync(lvi_lidar* h)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    return guarded(h, [&]() -> int32_t { sync(h->d); return LVI_OK; });
+}
+
+// ---- staged form ------------------------------------------------------------------------------
+int32_t lvi_scan_upload(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw)
+{
+    if (!h || (n_raw > 0 && !pts)) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (n_raw > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        d.n_raw = n_raw > 0 ? n_raw - 1 : 0;        // moveFromCustomMsg: i < point_num-1 (imageProjection.cpp:249)
+        h2d(d, d.raw, pts, (size_t)d.n_raw);
+        LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
+        sync(d);                                    // the caller's buffer may be reused after return
+        d.have_raw = true; d.have_org = d.have_feat = d.have_ds = false;
+        return LVI_OK;
+    });
+}
+int32_t lvi_scan_organize(lvi_lidar* h)
+{
+    if (!h || !h->d.have_raw) return fail(LVI_ERR_STATE, "no scan uploaded");
+    return guarded(h, [&]() -> int32_t { stage_organize(h->d); h->d.have_org = true; h->d.have_feat = h->d.have_ds = false; return LVI_OK; });
+}
+int32_t lvi_scan_extract(lvi_lidar* h)
+{
+    if (!h || !h->d.have_org) return fail(LVI_ERR_STATE, "scan not organised");
+    return guarded(h, [&]() -> int32_t { stage_extract(h->d); h->d.have_feat = true; h->d.have_ds = false; return LVI_OK; });
+}
+int32_t lvi_scan_downsample(lvi_lidar* h)
+{
+    if (!h || !h->d.have_feat) return fail(LVI_ERR_STATE, "features not extracted");
+    return guarded(h, [&]() -> int32_t { stage_downsample(h->d); h->d.have_ds = true; return LVI_OK; });
+}
+int32_t lvi_map_upload(lvi_lidar* h, const lvi_pt* c, int32_t nc, const lvi_pt* s, int32_t ns)
+{
+    if (!h || nc < 0 || ns < 0 || (nc > 0 && !c) || (ns > 0 && !s)) return fail(LVI_ERR_INVALID_ARG, "bad map arguments");
+    if (nc > h->d.map_cap || ns > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        h2d(d, d.mapCornerRaw, c, (size_t)nc); h2d(d, d.mapSurfRaw, s, (size_t)ns);
+        sync(d);
+        d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.have_map = false;
+        return LVI_OK;
+    });
+}
+int32_t lvi_map_build(lvi_lidar* h)
+{
+    if (!h || !h->d.have_map_raw) return fail(LVI_ERR_STATE, "no map uploaded");
+    return guarded(h, [&]() -> int32_t { stage_map_build(h->d); h->d.have_map = true; return LVI_OK; });
+}
+
+int32_t lvi_scan_match_async(lvi_lidar* h, const float pose_init[6], void* d_record)
+{
+    if (!h || !pose_init) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    return guarded(h, [&]() -> int32_t { stage_scan_match_enqueue(h->d, pose_init, nullptr, d_record); h->have_icp_host = false; return LVI_OK; });
+}
+
+int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi_icp_result* out)
+{
+    if (!h || !pose || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        stage_scan_match_enqueue(d, pose, imu, nullptr);
+        int nq[3] = {0, 0, 0};
+        d2h(d, d.h_icp, d.icp, 1);
+        d2h(d, nq, d.voxScan.d_nout, 3);
+        sync(d);
+        h->have_icp_host = true;
+        int32_t st = check_dev_status(d); if (st) return st;
+        const IcpState& s = *d.h_icp;
+        memset(out, 0, sizeof(*out));
+        out->status = s.status; out->iters = s.iters; out->converged = s.converged;
+        out->degenerate = s.degenerate; out->n_corner_ds = nq[0]; out->n_surf_ds = nq[1];
+        for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) out->n_sel[i] = s.n_sel[i];
+        for (int k = 0; k < 6; k++) { out->pose[k] = s.final_pose[k]; pose[k] = s.final_pose[k]; }
+        return s.status;
+    });
+}
+
+// ---- fetch ---------------------------------------------------------------------------------------
+int32_t lvi_get_scan_info(lvi_lidar* h, lvi_scan_info* out)
+{
+    if (!h || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->d.have_org) return fail(LVI_ERR_STATE, "scan not organised");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        const int n = read_int(d, d.d_n);
+        out->n = n;
+        if (out->capacity < n) return fail(LVI_ERR_CAPACITY, "scan_info capacity too small");
+        d2h(d, out->start_ring_index, d.startR, (size_t)d.P.N_SCAN); d2h(d, out->end_ring_index, d.endR, (size_t)d.P.N_SCAN);
+        d2h(d, out->point_col_ind, d.col, (size_t)n); d2h(d, out->point_range, d.range, (size_t)n); d2h(d, out->cloud_deskewed, d.pts, (size_t)n);
+        sync(d);
+        return LVI_OK;
+    });
+}
+int32_t lvi_get_features(lvi_lidar* h, lvi_cloud* corner, lvi_cloud* surf)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->d.have_feat) return fail(LVI_ERR_STATE, "features not extracted");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        int32_t st = check_dev_status(d); if (st) return st;
+        const Counts c = read_counts(d);
+        st = fetch_cloud(d, d.corner, c.ncorner, corner); if (st) return st;
+        return fetch_cloud(d, d.surf, c.nsurf, surf);
+    });
+}
+int32_t lvi_get_scan_ds(lvi_lidar* h, lvi_cloud* c0, lvi_cloud* c1)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        const Counts c = read_counts(d);
+        int32_t st = fetch_cloud(d, d.cornerDS, c.ncds, c0); if (st) return st;
+        return fetch_cloud(d, d.surfDS, c.nsds, c1);
+    });
+}
+int32_t lvi_get_map_ds(lvi_lidar* h, lvi_cloud* c0, lvi_cloud* c1)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->d.have_map) return fail(LVI_ERR_STATE, "map not built");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        int32_t st = check_dev_status(d); if (st) return st;
+        const Counts c = read_counts(d);
+        st = fetch_cloud(d, d.mapCornerDS, c.mcds, c0); if (st) return st;
+        return fetch_cloud(d, d.mapSurfDS, c.msds, c1);
+    });
+}
+int32_t lvi_get_counts(lvi_lidar* h, int32_t counts[8])
+{
+    if (!h || !counts) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    return guarded(h, [&]() -> int32_t {
+        const Counts c = read_counts(h->d);
+        counts[0] = c.n; counts[1] = c.ncorner; counts[2] = c.nsurf; counts[3] = c.ncds; counts[4] = c.nsds; counts[5] = c.mcds; counts[6] = c.msds; counts[7] = 0;
+        return LVI_OK;
+    });
+}
+
+// ---- one-call forms ------------------------------------------------------------------------------
+int32_t lvi_organize_scan(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw, lvi_scan_info* out)
+{
+    int32_t st = lvi_scan_upload(h, pts, n_raw); if (st) return st;
+    st = lvi_scan_organize(h); if (st) return st;
+    return lvi_get_scan_info(h, out);
+}
+
+int32_t lvi_extract_features(lvi_lidar* h, const lvi_scan_info* in, lvi_cloud* corner, lvi_cloud* surf)
+{
+    if (!h || !in) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (in->n < 0 || in->n > h->d.ext_cap) return fail(LVI_ERR_CAPACITY, "scan_info.n exceeds capacity");
+    int32_t st = guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        const int n = in->n, NS = d.P.N_SCAN;
+        // ring bases: start_ring_index[r] = count_r + 4 (imageProjection.cpp:630)
+        std::vector<int> base(NS + 1);
+        for (int r = 0; r < NS; r++) base[r] = in->start_ring_index[r] - 4;
+        base[NS] = n;
+        for (int r = 0; r < NS; r++) if (base[r] < 0 || base[r] > base[r + 1]) return fail(LVI_ERR_INVALID_ARG, "inconsistent ring indices");
+        h2d(d, d.pts, in->cloud_deskewed, (size_t)n); h2d(d, d.range, in->point_range, (size_t)n); h2d(d, d.col, in->point_col_ind, (size_t)n);
+        h2d(d, d.startR, in->start_ring_index, (size_t)NS); h2d(d, d.endR, in->end_ring_index, (size_t)NS);
+        h2d(d, d.ringBase, base.data(), (size_t)NS + 1); h2d(d, d.d_n, &n, 1);
+        LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
+        sync(d);
+        d.n_raw = n; d.have_org = true;
+        return LVI_OK;
+    });
+    if (st) return st;
+    st = lvi_scan_extract(h); if (st) return st;
+    return lvi_get_features(h, corner, surf);
+}
+
+int32_t lvi_voxel_downsample(lvi_lidar* h, const lvi_pt* in, int32_t n, float leaf, lvi_pt* out, int32_t out_capacity, int32_t* n_out)
+{
+    if (!h || n < 0 || (n > 0 && !in) || !(leaf > 0.f) || !n_out) return fail(LVI_ERR_INVALID_ARG, "bad voxel arguments");
+    if (n > h->d.voxGen.seg_cap) return fail(LVI_ERR_CAPACITY, "n exceeds capacity");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        h2d(d, d.genIn, in, (size_t)n);
+        VoxSegStatic st{d.genIn, nullptr, d.genOut, leaf};
+        d.voxGen.set_static(d.ctx, &st);
+        VoxSegDyn dyn{0, n};
+        h2d(d, d.voxGen.d_dyn, &dyn, 1);
+        sync(d);
+        voxel_downsample_batch(d.ctx, d.voxGen, "gen", n);
+        const int m = read_int(d, d.voxGen.d_nout);
+        *n_out = m;
+        voxel_debug_fetch(d.ctx, d.voxGen, n, h->vkeys, h->vcells, h->vcounts);
+        if (m > out_capacity) return fail(LVI_ERR_CAPACITY, "voxel output capacity too small");
+        d2h(d, out, d.genOut, (size_t)m);
+        sync(d);
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_map_set(lvi_lidar* h, const lvi_pt* c, int32_t nc, const lvi_pt* s, int32_t ns)
+{
+    int32_t st = lvi_map_upload(h, c, nc, s, ns); if (st) return st;
+    return lvi_map_build(h);
+}
+
+int32_t lvi_scan_to_map(lvi_lidar* h, const lvi_pt* corner, int32_t nc, const lvi_pt* surf, int32_t ns,
+                        const lvi_imu_hint* imu, float pose[6], lvi_icp_result* out)
+{
+    if (!h || nc < 0 || ns < 0 || (nc > 0 && !corner) || (ns > 0 && !surf)) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (nc > h->d.ext_cap || ns > h->d.ext_cap) return fail(LVI_ERR_CAPACITY, "feature clouds exceed capacity");
+    int32_t st = guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        h2d(d, d.corner, corner, (size_t)nc); h2d(d, d.surf, surf, (size_t)ns);
+        h2d(d, d.d_ncorner, &nc, 1); h2d(d, d.voxRing.d_nout + d.P.N_SCAN, &ns, 1);
+        sync(d);
+        d.n_raw = nc + ns; d.have_feat = true;
+        return LVI_OK;
+    });
+    if (st) return st;
+    st = lvi_scan_downsample(h); if (st) return st;
+    return lvi_scan_match(h, imu, pose, out);
+}
+
+int32_t lvi_transform_cloud(lvi_lidar* h, const lvi_pt* in, int32_t n, const float pose6[6], lvi_pt* out)
+{
+    if (!h || n < 0 || (n > 0 && (!in || !out)) || !pose6) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (n > h->d.voxGen.seg_cap) return fail(LVI_ERR_CAPACITY, "n exceeds capacity");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        h2d(d, d.genIn, in, (size_t)n);
+        transform_cloud(d, d.genIn, n, pose6, d.genOut);
+        d2h(d, out, d.genOut, (size_t)n);
+        sync(d);
+        return LVI_OK;
+    });
+}
+
+// ---- inspection ------------------------------------------------------------------------------------
+int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_t* n_bytes)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        auto need_feat = [&]() { return d.have_feat && d.have_org; };
+        switch (what) {
+            case LVI_DBG_CURVATURE: {
+                if (!need_feat()) return fail(LVI_ERR_STATE, "stage not run");
+                const int n = read_int(d, d.d_n);
+                std::vector<float> v(n); d2h(d, v.data(), d.curv, (size_t)n); sync(d);
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
+            case LVI_DBG_PICKED_OCCL: case LVI_DBG_PICKED_FINAL: case LVI_DBG_LABEL: {
+                if (!need_feat()) return fail(LVI_ERR_STATE, "stage not run");
+                const int n = read_int(d, d.d_n);
+                std::vector<int8_t> b(n);
+                const void* src = what == LVI_DBG_PICKED_OCCL ? (const void*)d.picked_occl : what == LVI_DBG_PICKED_FINAL ? (const void*)d.picked : (const void*)d.label;
+                if (n) LVI_HIP(hipMemcpyAsync(b.data(), src, (size_t)n, hipMemcpyDeviceToHost, d.ctx.stream));
+                sync(d);
+                std::vector<int32_t> v(n);
+                for (int i = 0; i < n; i++) v[i] = b[i];
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
+            case LVI_DBG_CORNER_INDEX: {
+                if (!need_feat()) return fail(LVI_ERR_STATE, "stage not run");
+                const int n = read_int(d, d.d_ncorner);
+                std::vector<int32_t> v(n); d2h(d, v.data(), d.corner_idx, (size_t)n); sync(d);
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
+            case LVI_DBG_VOXEL_KEYS: return dbg_out(h->vkeys, 0, dst, cap, n_bytes);
+            case LVI_DBG_VOXEL_CELLS: return dbg_out(h->vcells, 0, dst, cap, n_bytes);
+            case LVI_DBG_VOXEL_COUNTS: return dbg_out(h->vcounts, 0, dst, cap, n_bytes);
+            case LVI_DBG_ICP_JTJ: {
+                if (!h->have_icp_host) return fail(LVI_ERR_STATE, "scan_match not run");
+                std::vector<float> v(d.h_icp->jtj, d.h_icp->jtj + 27 * d.h_icp->iters);
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
+            case LVI_DBG_ICP_POSE_TRACE: {
+                if (!h->have_icp_host) return fail(LVI_ERR_STATE, "scan_match not run");
+                const int rows = d.h_icp->status == LVI_OK || d.h_icp->status == LVI_TOO_FEW_CORRESPONDENCES ? d.h_icp->iters + 1 : 0;
+                std::vector<float> v(d.h_icp->pose_trace, d.h_icp->pose_trace + 6 * rows);
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
+            default: return fail(LVI_ERR_INVALID_ARG, "unknown debug item");
+        }
+    });
+}
+
+int32_t lvi_debug_knn(lvi_lidar* h, int32_t which, const lvi_pt* queries, int32_t nq, int32_t* idx, float* sqd)
+{
+    if (!h || !queries || !idx || !sqd || nq < 0 || which < 0 || which > 1) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (!h->d.have_map) return fail(LVI_ERR_STATE, "map not built");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        lvi_pt* dq = nullptr; int* di = nullptr; float* dd = nullptr;
+        LVI_HIP(hipMalloc((void**)&dq, sizeof(lvi_pt) * std::max(nq, 1)));
+        LVI_HIP(hipMalloc((void**)&di, sizeof(int) * 5 * std::max(nq, 1)));
+        LVI_HIP(hipMalloc((void**)&dd, sizeof(float) * 5 * std::max(nq, 1)));
+        h2d(d, dq, queries, (size_t)nq);
+        debug_knn(d, which, dq, nq, di, dd);
+        d2h(d, idx, di, (size_t)nq * 5); d2h(d, sqd, dd, (size_t)nq * 5);
+        sync(d);
+        (void)hipFree(dq); (void)hipFree(di); (void)hipFree(dd);
+        return check_dev_status(d);
+    });
+}
+
+int32_t lvi_debug_residuals(lvi_lidar* h, int32_t which, const float pose[6], lvi_pt* coeff, uint8_t* flag, int32_t capacity, int32_t* n)
+{
+    if (!h || !pose || !coeff || !flag || !n || which < 0 || which > 1) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (!h->d.have_map || !h->d.have_ds) return fail(LVI_ERR_STATE, "map or scan DS missing");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        int nq[3];
+        d2h(d, nq, d.voxScan.d_nout, 3); sync(d);
+        *n = nq[which];
+        if (capacity < *n) return fail(LVI_ERR_CAPACITY, "capacity too small");
+        debug_residuals(d, which, pose);
+        d2h(d, coeff, d.coeff, (size_t)*n);
+        if (*n) LVI_HIP(hipMemcpyAsync(flag, d.flag, (size_t)*n, hipMemcpyDeviceToHost, d.ctx.stream));
+        sync(d);
+        return LVI_OK;
+    });
+}
+
+// ---- kernel timing -----------------------------------------------------------------------------------
+int32_t lvi_prof_enable(lvi_lidar* h, int32_t on)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    return guarded(h, [&]() -> int32_t { sync(h->d); h->d.prof.collect(); h->d.prof.on = on != 0; return LVI_OK; });
+}
+int32_t lvi_prof_reset(lvi_lidar* h)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    return guarded(h, [&]() -> int32_t { sync(h->d); h->d.prof.reset(); return LVI_OK; });
+}
+int32_t lvi_prof_read(lvi_lidar* h, lvi_kernel_stat* stats, int32_t capacity, int32_t* n)
+{
+    if (!h || !n) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    return guarded(h, [&]() -> int32_t {
+        Profiler& p = h->d.prof;
+        sync(h->d); p.collect();
+        int k = 0;
+        for (size_t i = 0; i < p.names.size(); i++) {
+            if (!p.launches[i]) continue;
+            if (k < capacity && stats) {
+                memset(&stats[k], 0, sizeof(stats[k]));
+                strncpy(stats[k].name, p.names[i].c_str(), sizeof(stats[k].name) - 1);
+                stats[k].launches = p.launches[i]; stats[k].total_ms = p.total_ms[i]; stats[k].bytes_alg = p.bytes[i];
+            }
+            k++;
+        }
+        *n = std::min(k, capacity);
+        return LVI_OK;
+    });
+}
+
+}  // extern "C"

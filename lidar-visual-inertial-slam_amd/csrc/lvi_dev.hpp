@@ -1,0 +1,171 @@
+// Internal header of liblvi_hip.so: HIP error handling, launch context with HIP-event
+// kernel timing, and the wave64 / workgroup primitives every kernel file uses.
+// gfx950 only: wavefront = 64 lanes, ballots are 64-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lvi_hotpath.h"
+
+namespace lvi {
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+void set_error(const std::string& s);                  // thread-local, read by lvi_last_error()
+
+struct HipError { hipError_t e; const char* what; const char* file; int line; };
+
+#define LVI_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (call);                                                               \
+        if (_e != hipSuccess) throw ::lvi::HipError{_e, #call, __FILE__, __LINE__};           \
+    } while (0)
+
+// one record per profiled launch
+struct ProfRec { int name_id; double bytes; hipEvent_t a, b; };
+
+struct Profiler {
+    bool on = false;
+    std::vector<std::string> names;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    // accumulated
+    std::vector<int64_t> launches;
+    std::vector<double> total_ms, bytes;
+
+    int name_id(const char* n);
+    hipEvent_t get_event();
+    void collect();          // sync + fold recs into the accumulators
+    void reset();
+    ~Profiler();
+};
+
+struct Ctx {
+    hipStream_t stream = nullptr;
+    Profiler* prof = nullptr;
+};
+
+// RAII bracket around one kernel launch: records HIP events on the launch stream when
+// profiling is on (this is what bench.py's roofline numbers come from).
+struct LaunchScope {
+    const Ctx& c; int id = -1; double bytes; hipEvent_t a = nullptr, b = nullptr;
+    LaunchScope(const Ctx& ctx, const char* name, double bytes_alg) : c(ctx), bytes(bytes_alg)
+    {
+        if (c.prof && c.prof->on) {
+            id = c.prof->name_id(name);
+            a = c.prof->get_event(); b = c.prof->get_event();
+            (void)hipEventRecord(a, c.stream);
+        }
+    }
+    ~LaunchScope()
+    {
+        if (id >= 0) { (void)hipEventRecord(b, c.stream); c.prof->recs.push_back(ProfRec{id, bytes, a, b}); }
+    }
+};
+#define LVI_LAUNCH(ctx, name, bytes, ...)                       \
+    do {                                                        \
+        ::lvi::LaunchScope _ls(ctx, name, (double)(bytes));     \
+        __VA_ARGS__;                                            \
+        LVI_HIP(hipGetLastError());                             \
+    } while (0)
+
+// bump allocator over one hipMalloc (all buffers live as long as the handle)
+struct Arena {
+    char* base = nullptr; size_t size = 0, used = 0;
+    void init(size_t bytes) { LVI_HIP(hipMalloc((void**)&base, bytes)); size = bytes; used = 0; }
+    template <class T> T* alloc(size_t n)
+    {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        if (used + bytes > size) throw HipError{hipErrorOutOfMemory, "arena exhausted", __FILE__, __LINE__};
+        T* p = reinterpret_cast<T*>(base + used); used += bytes; return p;
+    }
+    void release() { if (base) (void)hipFree(base); base = nullptr; }
+};
+// sizing pass: same calls, no memory
+struct ArenaSizer {
+    size_t used = 0;
+    template <class T> T* alloc(size_t n) { used += (n * sizeof(T) + 255) & ~size_t(255); return nullptr; }
+};
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------
+#define LVI_WAVE 64
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+template <class T>
+__device__ __forceinline__ T wave_incl_scan(T v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { T t = __shfl_up(v, o, 64); if (l >= o) v += t; }
+    return v;
+}
+template <class T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// workgroup exclusive scan of one int per thread; BLOCK threads (multiple of 64, <= 1024).
+// `ws` = shared scratch of BLOCK/64 + 1 ints.  Returns the exclusive prefix; *total = sum.
+template <int BLOCK>
+__device__ __forceinline__ int block_excl_scan(int v, int* ws, int* total)
+{
+    constexpr int NW = BLOCK / 64;
+    const int incl = wave_incl_scan(v);
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int w = (threadIdx.x < NW) ? ws[threadIdx.x] : 0;
+        int wi = wave_incl_scan(w);
+        if (threadIdx.x < NW) ws[threadIdx.x] = wi - w;
+        if (threadIdx.x == NW - 1) ws[NW] = wi;
+    }
+    __syncthreads();
+    const int r = ws[wave_id()] + incl - v;
+    if (total) *total = ws[NW];
+    __syncthreads();
+    return r;
+}
+
+// order-preserving float <-> uint encoding for atomicMin/atomicMax on floats
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
+// f32 arithmetic that must match the CPU restatement bit for bit: never contracted into FMA.
+// (The library is also compiled with -ffp-contract=off; these make the intent explicit.)
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float sqrt_rn(float a) { return __fsqrt_rn(a); }
+#endif  // __HIPCC__
+
+}  // namespace lvi

@@ -1,0 +1,720 @@
+// Map-side kernels of the lidar path for gfx950 (SURVEY §8 a-4(map) … a-10):
+//   map build   extractCloud's two VoxelGrid calls + the replacement of the two
+//               KdTreeFLANN::setInputCloud calls (mapOptimization.cpp:958-965, 1322-1323)
+//   residuals   cornerOptimization + surfOptimization, one thread per feature (:1006-1167)
+//   solve       combineOptimizationCoeffs + LMOptimization on the device (:1169-1313)
+//   finish      transformUpdate (:1345-1375)
+//
+// Exact 5-NN without a kd-tree: both callers discard a query unless its 5th neighbour is closer
+// than 1 m (sqDis[4] < 1.0, :1025,1121).  The DS map is binned into a uniform grid of >= 1 m cells
+// (cell ids computed in double so that floor() is exact); every map point with squared distance
+// < 1 to a query lies in the 3x3x3 block of cells around it, so scanning that block yields exactly
+// FLANN's answer for every query the reference accepts, and "fewer than 5 within 1 m" for the rest.
+// Distances are ((dx*dx)+dy*dy)+dz*dz in f32 without FMA, as FLANN's L2_Simple computes them.
+//
+// The Gauss-Newton loop never returns to the host: the 27 sums of AtA/AtB are reduced in double
+// (cv::gemm accumulates f32 products in double) to per-workgroup partials, summed in fixed order
+// by a one-wave solve kernel that also does the 6x6 QR solve, the iteration-0 eigen analysis,
+// the pose update and the convergence test, and prepares the next iteration's transform.
+#include "lvi_lidar.hpp"
+
+namespace lvi {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- grid index
+struct GridArgs {
+    GridIndex::Meta* meta[2];
+    const VoxGrid* vox;            // voxMap.d_grid (bbox of the raw map)
+    const int* nout;               // voxMap.d_nout
+    const lvi_pt* ds[2];
+    int* cell_start[2];
+    lvi_pt* sorted[2];
+    unsigned *keysA, *valsA, *keysB, *valsB;
+    int *d_n, *d_nbits;
+    int cap, max_cells;
+    int* d_status;
+};
+
+__global__ void grid_meta_kernel(GridArgs a)
+{
+    const int w = threadIdx.x;
+    if (w >= 2) return;
+    GridIndex::Meta& m = *a.meta[w];
+    const int n = a.nout[w];
+    m.n = n; m.ok = 0;
+    a.d_n[w] = n; a.d_nbits[w] = 0;
+    m.dim[0] = m.dim[1] = m.dim[2] = 1; m.ncells = 1; m.origin[0] = m.origin[1] = m.origin[2] = 0.0;
+    if (n <= 0 || a.vox[w].n_valid == 0) return;
+    double lo[3], ext[3];
+    for (int d = 0; d < 3; d++) {
+        const double mn = floor((double)ord2f(a.vox[w].bb[d])), mx = floor((double)ord2f(a.vox[w].bb[3 + d]));
+        lo[d] = mn - 1.0;                       // one cell of padding on every side
+        ext[d] = mx - mn + 3.0;
+    }
+    int c = 1;                                  // cell edge in metres, integer >= 1
+    for (;; c++) {
+        const double nx = ceil(ext[0] / c), ny = ceil(ext[1] / c), nz = ceil(ext[2] / c);
+        if (nx * ny * nz <= (double)a.max_cells) { m.dim[0] = (int)nx; m.dim[1] = (int)ny; m.dim[2] = (int)nz; break; }
+        if (c > 1 << 20) { atomicOr(a.d_status, DEV_ERR_GRID_TOO_LARGE); return; }
+    }
+    // the cell edge is folded into the origin/scale: cell = floor((p - lo) / c)
+    m.origin[0] = lo[0]; m.origin[1] = lo[1]; m.origin[2] = lo[2];
+    m.ncells = m.dim[0] * m.dim[1] * m.dim[2];
+    m.ok = c;                                   // ok holds the cell edge (>= 1)
+    a.d_nbits[w] = (m.ncells <= 1) ? 0 : (32 - __clz((unsigned)(m.ncells - 1)));
+}
+
+__device__ __forceinline__ void cell_of(const GridIndex::Meta& m, float x, float y, float z, int c[3])
+{
+    const double e = (double)m.ok;
+    c[0] = (int)floor(((double)x - m.origin[0]) / e);
+    c[1] = (int)floor(((double)y - m.origin[1]) / e);
+    c[2] = (int)floor(((double)z - m.origin[2]) / e);
+}
+
+__global__ __launch_bounds__(256) void grid_keys_kernel(GridArgs a)
+{
+    const int w = blockIdx.y;
+    const GridIndex::Meta& m = *a.meta[w];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m.n || !m.ok) return;
+    const lvi_pt p = a.ds[w][i];
+    int c[3];
+    cell_of(m, p.x, p.y, p.z, c);
+#pragma unroll
+    for (int d = 0; d < 3; d++) c[d] = min(max(c[d], 0), m.dim[d] - 1);
+    a.keysA[(size_t)w * a.cap + i] = (unsigned)((c[2] * m.dim[1] + c[1]) * m.dim[0] + c[0]);
+    a.valsA[(size_t)w * a.cap + i] = (unsigned)i;
+}
+
+// cell_start[c] = first sorted position whose cell id >= c (lower bound), for c in [0, ncells]
+__global__ __launch_bounds__(256) void grid_fill_kernel(GridArgs a)
+{
+    const int w = blockIdx.y;
+    const GridIndex::Meta& m = *a.meta[w];
+    const unsigned* keys = (rs_result_in_B(a.d_nbits[w]) ? a.keysB : a.keysA) + (size_t)w * a.cap;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c <= m.ncells; c += gridDim.x * 256) {
+        int lo = 0, hi = m.ok ? m.n : 0;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < (unsigned)c) lo = mid + 1; else hi = mid; }
+        a.cell_start[w][c] = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_gather_kernel(GridArgs a)
+{
+    const int w = blockIdx.y;
+    const GridIndex::Meta& m = *a.meta[w];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m.n || !m.ok) return;
+    const unsigned* vals = (rs_result_in_B(a.d_nbits[w]) ? a.valsB : a.valsA) + (size_t)w * a.cap;
+    const unsigned src = vals[i];
+    lvi_pt p = a.ds[w][src];
+    p.intensity = __int_as_float((int)src);     // original index in laserCloud*FromMapDS
+    a.sorted[w][i] = p;
+}
+
+// ------------------------------------------------------------------------------------------- 5-NN
+struct Knn5 { float d[5]; int i[5]; };
+
+__device__ __forceinline__ void knn_insert(Knn5& r, float dist, int idx)
+{
+    // ascending by (distance, index)
+    if (!(dist < r.d[4] || (dist == r.d[4] && idx < r.i[4]))) return;
+    r.d[4] = dist; r.i[4] = idx;
+#pragma unroll
+    for (int k = 4; k > 0; k--) {
+        const bool sw = (r.d[k] < r.d[k - 1]) || (r.d[k] == r.d[k - 1] && r.i[k] < r.i[k - 1]);
+        if (sw) { const float td = r.d[k]; r.d[k] = r.d[k - 1]; r.d[k - 1] = td; const int ti = r.i[k]; r.i[k] = r.i[k - 1]; r.i[k - 1] = ti; }
+    }
+}
+
+__device__ __forceinline__ void knn5_search(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
+                                            float qx, float qy, float qz, Knn5& r)
+{
+#pragma unroll
+    for (int k = 0; k < 5; k++) { r.d[k] = INFINITY; r.i[k] = 0x7fffffff; }
+    if (!m.ok || m.n <= 0) return;
+    int c[3];
+    cell_of(m, qx, qy, qz, c);
+    const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, m.dim[0] - 1);
+    if (x0 > x1) return;
+    for (int dz = -1; dz <= 1; dz++) {
+        const int z = c[2] + dz;
+        if (z < 0 || z >= m.dim[2]) continue;
+        for (int dy = -1; dy <= 1; dy++) {
+            const int y = c[1] + dy;
+            if (y < 0 || y >= m.dim[1]) continue;
+            const int row = (z * m.dim[1] + y) * m.dim[0];
+            const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
+            for (int j = b; j < e; j++) {
+                const lvi_pt p = sorted[j];
+                const float ex = sub_rn(qx, p.x), ey = sub_rn(qy, p.y), ez = sub_rn(qz, p.z);
+                const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+                knn_insert(r, dist, __float_as_int(p.intensity));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_debug_kernel(const GridIndex::Meta* meta, const int* cell_start, const lvi_pt* sorted,
+                                                        const lvi_pt* q, int nq, int* idx, float* sqd)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nq) return;
+    Knn5 r;
+    knn5_search(*meta, cell_start, sorted, q[t].x, q[t].y, q[t].z, r);
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const bool ok = r.d[k] < 1.0f;
+        idx[t * 5 + k] = ok ? r.i[k] : -1;
+        sqd[t * 5 + k] = ok ? r.d[k] : INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- small matrices
+// symmetric 3x3 eigen-decomposition, cyclic Jacobi in f32: eigenvalues descending, v0 = eigenvector of the largest
+__device__ void eig3_sym(float a11, float a12, float a13, float a22, float a23, float a33, float ev[3], float v0[3])
+{
+    float A[3][3] = {{a11, a12, a13}, {a12, a22, a23}, {a13, a23, a33}};
+    float V[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+    for (int sweep = 0; sweep < 12; sweep++) {
+        const float off = fabsf(A[0][1]) + fabsf(A[0][2]) + fabsf(A[1][2]);
+        const float dia = fabsf(A[0][0]) + fabsf(A[1][1]) + fabsf(A[2][2]);
+        if (off <= 1e-12f * dia || off == 0.f) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; pq++) {
+            const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+            const float apq = A[p][q];
+            if (apq == 0.f) continue;
+            const float theta = (A[q][q] - A[p][p]) / (2.f * apq);
+            const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+            const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+            A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.f;
+            const int r = 3 - p - q;
+            const float arp = A[r][p], arq = A[r][q];
+            A[r][p] = A[p][r] = c * arp - s * arq;
+            A[r][q] = A[q][r] = s * arp + c * arq;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const float vp = V[k][p], vq = V[k][q]; V[k][p] = c * vp - s * vq; V[k][q] = s * vp + c * vq; }
+        }
+    }
+    const float l0 = A[0][0], l1 = A[1][1], l2 = A[2][2];
+    const int i0 = (l0 >= l1 && l0 >= l2) ? 0 : (l1 >= l2 ? 1 : 2);
+    ev[0] = i0 == 0 ? l0 : (i0 == 1 ? l1 : l2);
+    ev[1] = i0 == 0 ? fmaxf(l1, l2) : (i0 == 1 ? fmaxf(l0, l2) : fmaxf(l0, l1));
+    ev[2] = i0 == 0 ? fminf(l1, l2) : (i0 == 1 ? fminf(l0, l2) : fminf(l0, l1));
+#pragma unroll
+    for (int k = 0; k < 3; k++) v0[k] = i0 == 0 ? V[k][0] : (i0 == 1 ? V[k][1] : V[k][2]);
+}
+
+// least squares of the 5x3 system A x = b by Householder QR with column pivoting (f32)
+__device__ void lstsq_5x3(float A[5][3], float b[5], float x[3])
+{
+    int perm[3] = {0, 1, 2};
+    int rank = 3;
+    float thr0 = 0.f;
+    for (int j = 0; j < 3; j++) { float s = 0.f; for (int i = 0; i < 5; i++) s += A[i][j] * A[i][j]; thr0 = fmaxf(thr0, sqrtf(s)); }
+    const float thr = (thr0 * 1.1920929e-7f) * (thr0 * 1.1920929e-7f) / 5.f;
+    for (int k = 0; k < 3; k++) {
+        int big = k; float bigsq = -1.f;
+        for (int j = k; j < 3; j++) { float s = 0.f; for (int i = k; i < 5; i++) s += A[i][j] * A[i][j]; if (s > bigsq) { bigsq = s; big = j; } }
+        if (rank == 3 && bigsq < thr * (float)(5 - k)) rank = k;
+        if (big != k) { for (int i = 0; i < 5; i++) { const float t = A[i][k]; A[i][k] = A[i][big]; A[i][big] = t; } const int t = perm[k]; perm[k] = perm[big]; perm[big] = t; }
+        const float c0 = A[k][k];
+        float tail = 0.f; for (int i = k + 1; i < 5; i++) tail += A[i][k] * A[i][k];
+        float tau, beta;
+        if (tail <= 1.17549435e-38f) { tau = 0.f; beta = c0; for (int i = k + 1; i < 5; i++) A[i][k] = 0.f; }
+        else {
+            beta = sqrtf(c0 * c0 + tail); if (c0 >= 0.f) beta = -beta;
+            for (int i = k + 1; i < 5; i++) A[i][k] /= (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        A[k][k] = beta;
+        for (int j = k + 1; j < 3; j++) {
+            float s = 0.f; for (int i = k + 1; i < 5; i++) s += A[i][k] * A[i][j];
+            s += A[k][j]; s *= tau; A[k][j] -= s;
+            for (int i = k + 1; i < 5; i++) A[i][j] -= s * A[i][k];
+        }
+        float s = 0.f; for (int i = k + 1; i < 5; i++) s += A[i][k] * b[i];
+        s += b[k]; s *= tau; b[k] -= s;
+        for (int i = k + 1; i < 5; i++) b[i] -= s * A[i][k];
+    }
+    float c[3] = {0.f, 0.f, 0.f};
+    for (int i = rank - 1; i >= 0; i--) { float s = b[i]; for (int j = i + 1; j < rank; j++) s -= A[i][j] * c[j]; c[i] = s / A[i][i]; }
+    x[0] = x[1] = x[2] = 0.f;
+    for (int i = 0; i < rank; i++) x[perm[i]] = c[i];
+}
+
+// ------------------------------------------------------------------------------------------- residuals
+struct IcpArgs {
+    IcpState* st;
+    const lvi_pt* q[2]; const int* nq;            // cornerDS / surfDS, voxScan.d_nout
+    const GridIndex::Meta* meta[2]; const int* cell_start[2]; const lvi_pt* sorted[2];
+    const lvi_pt* mapds[2];
+    lvi_pt* coeff; uint8_t* flag; double* partial;
+    int edgeMin, surfMin, max_iters, disable_break;
+    float rot_tol, z_tol; double imu_weight;
+    int imu_available; float imu_roll, imu_pitch;
+    void* d_record;
+};
+
+__device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
+{
+    lvi_pt o;
+    o.x = A[0] * p.x + A[1] * p.y + A[2] * p.z + A[3];
+    o.y = A[4] * p.x + A[5] * p.y + A[6] * p.z + A[7];
+    o.z = A[8] * p.x + A[9] * p.y + A[10] * p.z + A[11];
+    o.intensity = p.intensity;
+    return o;
+}
+
+__device__ bool corner_residual(const IcpArgs& a, const float A[12], const lvi_pt& pointOri, lvi_pt& coeff)
+{
+    const lvi_pt pointSel = to_map(A, pointOri);
+    Knn5 r;
+    knn5_search(*a.meta[0], a.cell_start[0], a.sorted[0], pointSel.x, pointSel.y, pointSel.z, r);
+    if (!(r.d[4] < 1.0f)) return false;                                            // :1025
+    const lvi_pt* map = a.mapds[0];
+    float cx = 0, cy = 0, cz = 0;
+    lvi_pt nb[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { nb[j] = map[r.i[j]]; cx += nb[j].x; cy += nb[j].y; cz += nb[j].z; }
+    cx /= 5; cy /= 5; cz /= 5;
+    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const float ax = nb[j].x - cx, ay = nb[j].y - cy, az = nb[j].z - cz;
+        a11 += ax * ax; a12 += ax * ay; a13 += ax * az; a22 += ay * ay; a23 += ay * az; a33 += az * az;
+    }
+    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+    float ev[3], v0[3];
+    eig3_sym(a11, a12, a13, a22, a23, a33, ev, v0);                                // cv::eigen :1050
+    if (!(ev[0] > 3 * ev[1])) return false;
+    const float x0 = pointSel.x, y0 = pointSel.y, z0 = pointSel.z;
+    const float x1 = cx + 0.1 * v0[0], y1 = cy + 0.1 * v0[1], z1 = cz + 0.1 * v0[2];
+    const float x2 = cx - 0.1 * v0[0], y2 = cy - 0.1 * v0[1], z2 = cz - 0.1 * v0[2];
+    const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+    const float m12 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+    const float m13 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+    const float a012 = sqrtf(m11 * m11 + m12 * m12 + m13 * m13);
+    const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+    const float la = ((y1 - y2) * m11 + (z1 - z2) * m12) / a012 / l12;
+    const float lb = -((x1 - x2) * m11 - (z1 - z2) * m13) / a012 / l12;
+    const float lc = -((x1 - x2) * m12 + (y1 - y2) * m13) / a012 / l12;
+    const float ld2 = a012 / l12;
+    const float s = 1 - 0.9 * fabsf(ld2);
+    coeff.x = s * la; coeff.y = s * lb; coeff.z = s * lc; coeff.intensity = s * ld2;
+    return s > 0.1;
+}
+
+__device__ bool surf_residual(const IcpArgs& a, const float A[12], const lvi_pt& pointOri, lvi_pt& coeff)
+{
+    const lvi_pt pointSel = to_map(A, pointOri);
+    Knn5 r;
+    knn5_search(*a.meta[1], a.cell_start[1], a.sorted[1], pointSel.x, pointSel.y, pointSel.z, r);
+    if (!(r.d[4] < 1.0f)) return false;                                            // :1121
+    const lvi_pt* map = a.mapds[1];
+    float M[5][3], b[5], X[3];
+    lvi_pt nb[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { nb[j] = map[r.i[j]]; M[j][0] = nb[j].x; M[j][1] = nb[j].y; M[j][2] = nb[j].z; b[j] = -1.f; }
+    lstsq_5x3(M, b, X);                                                            // colPivHouseholderQr().solve :1128
+    float pa = X[0], pb = X[1], pc = X[2], pd = 1;
+    const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
+    pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+        if (fabsf(pa * nb[j].x + pb * nb[j].y + pc * nb[j].z + pd) > 0.2) return false;
+    const float pd2 = pa * pointSel.x + pb * pointSel.y + pc * pointSel.z + pd;
+    const float s = 1 - 0.9 * fabsf(pd2) / sqrtf(sqrtf(pointOri.x * pointOri.x + pointOri.y * pointOri.y + pointOri.z * pointOri.z));
+    coeff.x = s * pa; coeff.y = s * pb; coeff.z = s * pc; coeff.intensity = s * pd2;
+    return s > 0.1;
+}
+
+// one Gauss-Newton row: matA(i, 0..5), matB(i) (LMOptimization :1224-1255)
+__device__ __forceinline__ void lm_row(const float tr[6], const lvi_pt& ori, const lvi_pt& cf, float rowA[6], float& rowB)
+{
+    const float srx = tr[0], crx = tr[1], sry = tr[2], cry = tr[3], srz = tr[4], crz = tr[5];
+    const float px = ori.y, py = ori.z, pz = ori.x;          // lidar -> camera
+    const float cx = cf.y, cy = cf.z, cz = cf.x;
+    const float arx = (crx * sry * srz * px + crx * crz * sry * py - srx * sry * pz) * cx
+                    + (-srx * srz * px - crz * srx * py - crx * pz) * cy
+                    + (crx * cry * srz * px + crx * cry * crz * py - cry * srx * pz) * cz;
+    const float ary = ((cry * srx * srz - crz * sry) * px + (sry * srz + cry * crz * srx) * py + crx * cry * pz) * cx
+                    + ((-cry * crz - srx * sry * srz) * px + (cry * srz - crz * srx * sry) * py - crx * sry * pz) * cz;
+    const float arz = ((crz * srx * sry - cry * srz) * px + (-cry * crz - srx * sry * srz) * py) * cx
+                    + (crx * crz * px - crx * srz * py) * cy
+                    + ((sry * srz + cry * crz * srx) * px + (crz * sry - cry * srx * srz) * py) * cz;
+    rowA[0] = arz; rowA[1] = arx; rowA[2] = ary; rowA[3] = cz; rowA[4] = cx; rowA[5] = cy;
+    rowB = -cf.intensity;
+}
+
+__global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
+{
+    if (a.st->done) return;
+    const int nC = a.nq[0], nS = a.nq[1];
+    const int t = blockIdx.x * ICP_BLOCK + threadIdx.x;
+    if (blockIdx.x * ICP_BLOCK >= nC + nS) return;
+    __shared__ float sA[12], sT[6];
+    if (threadIdx.x < 12) sA[threadIdx.x] = a.st->pose.A[threadIdx.x];
+    if (threadIdx.x < 6) sT[threadIdx.x] = a.st->pose.trig[threadIdx.x];
+    __syncthreads();
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0.0;
+    if (t < nC + nS) {
+        const bool isC = t < nC;
+        const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
+        lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
+        const bool ok = isC ? corner_residual(a, sA, ori, cf) : surf_residual(a, sA, ori, cf);
+        a.flag[t] = ok ? 1 : 0;
+        a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            float rA[6], rB;
+            lm_row(sT, ori, cf, rA, rB);
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = r; c < 6; c++) acc[k++] = (double)rA[r] * (double)rA[c];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[21 + r] = (double)rA[r] * (double)rB;
+            acc[27] = 1.0;
+        }
+    }
+    __shared__ double sred[ICP_BLOCK / 64][28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) { const double v = wave_sum(acc[k]); if (lane_id() == 0) sred[wave_id()][k] = v; }
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < ICP_BLOCK / 64; w++) v += sred[w][threadIdx.x];
+        a.partial[blockIdx.x * 28 + threadIdx.x] = v;
+    }
+}
+
+__device__ void make_pose(IcpPose& p)
+{
+    // pcl::getTransformation(x,y,z,roll,pitch,yaw) (trans2Affine3f :404-407)
+    const float roll = p.T[0], pitch = p.T[1], yaw = p.T[2];
+    const float A = cosf(yaw), B = sinf(yaw), C = cosf(pitch), D = sinf(pitch), E = cosf(roll), F = sinf(roll), DE = D * E, DF = D * F;
+    p.A[0] = A * C; p.A[1] = A * DF - B * E; p.A[2] = B * F + A * DE; p.A[3] = p.T[3];
+    p.A[4] = B * C; p.A[5] = A * E + B * DF; p.A[6] = B * DE - A * F; p.A[7] = p.T[4];
+    p.A[8] = -D;    p.A[9] = C * F;          p.A[10] = C * E;         p.A[11] = p.T[5];
+    // LMOptimization :1202-1207 — srx from pitch, sry from yaw, srz from roll
+    p.trig[0] = sinf(p.T[1]); p.trig[1] = cosf(p.T[1]);
+    p.trig[2] = sinf(p.T[2]); p.trig[3] = cosf(p.T[2]);
+    p.trig[4] = sinf(p.T[0]); p.trig[5] = cosf(p.T[0]);
+}
+
+__global__ void icp_init_kernel(IcpArgs a, float t0, float t1, float t2, float t3, float t4, float t5, int have_map)
+{
+    IcpState& s = *a.st;
+    s.pose.T[0] = t0; s.pose.T[1] = t1; s.pose.T[2] = t2; s.pose.T[3] = t3; s.pose.T[4] = t4; s.pose.T[5] = t5;
+    make_pose(s.pose);
+    s.done = 0; s.converged = 0; s.iters = 0; s.any_lm = 0; s.status = LVI_OK;
+    for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) s.n_sel[i] = 0;
+    if (!have_map) { s.done = 1; s.status = LVI_NO_MAP; return; }                              // :1317
+    if (!(a.nq[0] > a.edgeMin && a.nq[1] > a.surfMin)) { s.done = 1; s.status = LVI_TOO_FEW_FEATURES; }   // :1320
+}
+
+// Householder QR solve of the 6x6 system (cv::solve DECOMP_QR, :1260), f32
+__device__ bool solve6_qr(float A[6][6], float b[6])
+{
+    float vl[6], hF[6];
+    for (int l = 0; l < 6; l++) {
+        float nrm = 0.f;
+        for (int i = l; i < 6; i++) { vl[i] = A[i][l]; nrm += vl[i] * vl[i]; }
+        const float t0 = vl[l];
+        vl[l] = vl[l] + (vl[l] >= 0.f ? 1.f : -1.f) * sqrtf(nrm);
+        nrm = sqrtf(nrm + vl[l] * vl[l] - t0 * t0);
+        if (nrm == 0.f) return false;
+        for (int i = l; i < 6; i++) vl[i] /= nrm;
+        for (int j = l; j < 6; j++) {
+            float s = 0.f; for (int i = l; i < 6; i++) s += vl[i] * A[i][j];
+            for (int i = l; i < 6; i++) A[i][j] -= 2 * vl[i] * s;
+        }
+        float s = 0.f; for (int i = l; i < 6; i++) s += vl[i] * b[i];
+        for (int i = l; i < 6; i++) b[i] -= 2 * vl[i] * s;
+        hF[l] = 0.f;
+    }
+    (void)hF;
+    for (int i = 5; i >= 0; i--) {
+        for (int j = 5; j > i; j--) b[i] -= b[j] * A[i][j];
+        if (fabsf(A[i][i]) < 1.1920929e-6f) return false;
+        b[i] /= A[i][i];
+    }
+    return true;
+}
+
+// symmetric 6x6 eigen-decomposition (cv::eigen :1268), cyclic Jacobi f32; W descending, rows of V = eigenvectors
+__device__ void eig6_sym(float A[6][6], float W[6], float V[6][6])
+{
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.f : 0.f;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        float off = 0.f, dia = 0.f;
+        for (int i = 0; i < 6; i++) { dia += fabsf(A[i][i]); for (int j = i + 1; j < 6; j++) off += fabsf(A[i][j]); }
+        if (off <= 1e-10f * dia || off == 0.f) break;
+        for (int p = 0; p < 5; p++)
+            for (int q = p + 1; q < 6; q++) {
+                const float apq = A[p][q];
+                if (apq == 0.f) continue;
+                const float theta = (A[q][q] - A[p][p]) / (2.f * apq);
+                const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+                const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+                A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.f;
+                for (int r = 0; r < 6; r++) {
+                    if (r == p || r == q) continue;
+                    const float arp = A[r][p], arq = A[r][q];
+                    A[r][p] = A[p][r] = c * arp - s * arq;
+                    A[r][q] = A[q][r] = s * arp + c * arq;
+                }
+                for (int k = 0; k < 6; k++) { const float vp = V[p][k], vq = V[q][k]; V[p][k] = c * vp - s * vq; V[q][k] = s * vp + c * vq; }
+            }
+    }
+    for (int i = 0; i < 6; i++) W[i] = A[i][i];
+    for (int k = 0; k < 5; k++) {
+        int m = k;
+        for (int i = k + 1; i < 6; i++) if (W[m] < W[i]) m = i;
+        if (m != k) { const float t = W[m]; W[m] = W[k]; W[k] = t; for (int i = 0; i < 6; i++) { const float u = V[m][i]; V[m][i] = V[k][i]; V[k][i] = u; } }
+    }
+}
+
+__global__ __launch_bounds__(64) void icp_solve_kernel(IcpArgs a, int iter)
+{
+    IcpState& s = *a.st;
+    if (s.done) return;
+    __shared__ double sums[28];
+    const int Q = a.nq[0] + a.nq[1];
+    const int nb = (Q + ICP_BLOCK - 1) / ICP_BLOCK;
+    if (threadIdx.x < 28) {
+        double v = 0.0;
+        for (int b = 0; b < nb; b++) v += a.partial[b * 28 + threadIdx.x];      // fixed order → run-to-run reproducible
+        sums[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int nsel = (int)sums[27];
+    s.n_sel[iter] = nsel;
+    s.iters = iter + 1;
+    for (int k = 0; k < 6; k++) s.pose_trace[iter * 6 + k] = s.pose.T[k];
+    for (int k = 0; k < 27; k++) s.jtj[iter * 27 + k] = (float)sums[k];
+    if (nsel >= 50) {                                                            // :1210
+        s.any_lm = 1;
+        float AtA[6][6], X[6];
+        {
+            int k = 0;
+            for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { AtA[r][c] = AtA[c][r] = (float)sums[k++]; }
+            for (int r = 0; r < 6; r++) X[r] = (float)sums[21 + r];
+        }
+        {
+            float Ac[6][6];
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Ac[r][c] = AtA[r][c];
+            if (!solve6_qr(Ac, X)) for (int r = 0; r < 6; r++) X[r] = 0.f;
+        }
+        float matP[6][6];
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) matP[r][c] = 0.f;  // local matP shadows the member
+        if (iter == 0) {
+            float W[6], V[6][6], V2[6][6], Ac[6][6];
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Ac[r][c] = AtA[r][c];
+            eig6_sym(Ac, W, V);
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) V2[r][c] = V[r][c];
+            s.degenerate = 0;
+            for (int i = 5; i >= 0; i--) {
+                if (W[i] < 100.f) { for (int j = 0; j < 6; j++) V2[i][j] = 0.f; s.degenerate = 1; }
+                else break;
+            }
+            // matP = matV.inv() * matV2; V is orthogonal, inv(V) = V^T
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { double acc = 0; for (int k = 0; k < 6; k++) acc += (double)V[k][r] * (double)V2[k][c]; matP[r][c] = (float)acc; }
+        }
+        if (s.degenerate) {
+            float X2[6];
+            for (int r = 0; r < 6; r++) X2[r] = X[r];
+            for (int r = 0; r < 6; r++) { double acc = 0; for (int k = 0; k < 6; k++) acc += (double)matP[r][k] * (double)X2[k]; X[r] = (float)acc; }
+        }
+        for (int r = 0; r < 6; r++) s.pose.T[r] += X[r];
+        const double dR = sqrt(pow((double)(X[0] * 57.29578f), 2.0) + pow((double)(X[1] * 57.29578f), 2.0) + pow((double)(X[2] * 57.29578f), 2.0));
+        const double dT = sqrt(pow((double)(X[3] * 100), 2.0) + pow((double)(X[4] * 100), 2.0) + pow((double)(X[5] * 100), 2.0));
+        const float deltaR = (float)dR, deltaT = (float)dT;
+        if (deltaR < 0.05 && deltaT < 0.05) {                                    // :1309
+            s.converged = 1;
+            if (!a.disable_break) s.done = 1;
+        }
+        make_pose(s.pose);
+    }
+}
+
+// tf2 pieces of transformUpdate (doubles)
+struct Quatd { double x, y, z, w; };
+__device__ Quatd q_rpy(double roll, double pitch, double yaw)
+{
+    const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+    return Quatd{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+}
+__device__ double q_dot(const Quatd& a, const Quatd& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ Quatd q_slerp(const Quatd& a, const Quatd& q, double t)
+{
+    const double s = sqrt(q_dot(a, a) * q_dot(q, q));
+    const double d = q_dot(a, q);
+    const double theta = ((d < 0) ? acos(-d / s) * 2.0 : acos(d / s) * 2.0) / 2.0;
+    if (theta != 0.0) {
+        const double dd = 1.0 / sin(theta), s0 = sin((1.0 - t) * theta), s1 = sin(t * theta);
+        const double sg = (d < 0) ? -1.0 : 1.0;
+        return Quatd{(a.x * s0 + sg * q.x * s1) * dd, (a.y * s0 + sg * q.y * s1) * dd, (a.z * s0 + sg * q.z * s1) * dd, (a.w * s0 + sg * q.w * s1) * dd};
+    }
+    return a;
+}
+__device__ void q_to_rpy(const Quatd& q, double& roll, double& pitch, double& yaw)
+{
+    const double s = 2.0 / q_dot(q, q);
+    const double xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    const double wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs, yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+    if (fabs(m20) >= 1) { yaw = 0; roll = atan2(m21, m22); pitch = (m20 < 0) ? M_PI / 2.0 : -M_PI / 2.0; }
+    else { pitch = -asin(m20); roll = atan2(m21 / cos(pitch), m22 / cos(pitch)); yaw = atan2(m10 / cos(pitch), m00 / cos(pitch)); }
+}
+
+__global__ void icp_finish_kernel(IcpArgs a)
+{
+    IcpState& s = *a.st;
+    float* T = s.pose.T;
+    const bool ran = (s.status == LVI_OK);
+    if (ran) {
+        for (int k = 0; k < 6; k++) s.pose_trace[s.iters * 6 + k] = T[k];
+        if (a.imu_available && fabsf(a.imu_pitch) < 1.4f) {                       // transformUpdate :1347-1367
+            double r, p, y;
+            q_to_rpy(q_slerp(q_rpy(T[0], 0, 0), q_rpy(a.imu_roll, 0, 0), a.imu_weight), r, p, y);
+            T[0] = (float)r;
+            q_to_rpy(q_slerp(q_rpy(0, T[1], 0), q_rpy(0, a.imu_pitch, 0), a.imu_weight), r, p, y);
+            T[1] = (float)p;
+        }
+        T[0] = fminf(fmaxf(T[0], -a.rot_tol), a.rot_tol);                         // :1370-1372
+        T[1] = fminf(fmaxf(T[1], -a.rot_tol), a.rot_tol);
+        T[5] = fminf(fmaxf(T[5], -a.z_tol), a.z_tol);
+        if (!s.any_lm) s.status = LVI_TOO_FEW_CORRESPONDENCES;
+    }
+    for (int k = 0; k < 6; k++) { s.final_pose[k] = T[k]; s.record.pose[k] = T[k]; }
+    s.record.status = s.status; s.record.iters = s.iters;
+    if (a.d_record) *reinterpret_cast<lvi_pose_record*>(a.d_record) = s.record;
+}
+
+__global__ __launch_bounds__(256) void transform_kernel(const lvi_pt* in, int n, IcpPose pose, lvi_pt* out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = to_map(pose.A, in[i]);
+}
+
+__global__ void pose_only_kernel(IcpPose* out, float t0, float t1, float t2, float t3, float t4, float t5)
+{
+    IcpPose p;
+    p.T[0] = t0; p.T[1] = t1; p.T[2] = t2; p.T[3] = t3; p.T[4] = t4; p.T[5] = t5;
+    make_pose(p);
+    *out = p;
+}
+
+__global__ __launch_bounds__(256) void transform_dev_pose_kernel(const lvi_pt* in, int n, const IcpPose* pose, lvi_pt* out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = to_map(pose->A, in[i]);
+}
+
+__global__ __launch_bounds__(ICP_BLOCK) void residual_debug_kernel(IcpArgs a, int which, const IcpPose* pose)
+{
+    const int n = a.nq[which];
+    const int t = blockIdx.x * ICP_BLOCK + threadIdx.x;
+    if (t >= n) return;
+    lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
+    const bool ok = which == 0 ? corner_residual(a, pose->A, a.q[0][t], cf) : surf_residual(a, pose->A, a.q[1][t], cf);
+    a.flag[t] = ok ? 1 : 0;
+    a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+}
+
+__global__ void set_dyn2_kernel(VoxSegDyn* dyn, int n0, int n1)
+{
+    dyn[0].in_off = 0; dyn[0].n = n0;
+    dyn[1].in_off = 0; dyn[1].n = n1;
+}
+
+IcpArgs icp_args(LidarDev& d)
+{
+    IcpArgs a{};
+    a.st = d.icp;
+    a.q[0] = d.cornerDS; a.q[1] = d.surfDS; a.nq = d.voxScan.d_nout;
+    for (int w = 0; w < 2; w++) { a.meta[w] = d.grid[w].meta; a.cell_start[w] = d.grid[w].cell_start; a.sorted[w] = d.grid[w].sorted; }
+    a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
+    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial;
+    a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
+    a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
+    a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;
+    return a;
+}
+
+}  // namespace
+
+void stage_map_build(LidarDev& d)
+{
+    // raw map counts are host-known here; the voxel plan wants them in device memory
+    hipLaunchKernelGGL(set_dyn2_kernel, dim3(1), dim3(1), 0, d.ctx.stream, d.voxMap.d_dyn, d.n_map_corner, d.n_map_surf);
+    const double n = (double)d.n_map_corner + (double)d.n_map_surf;
+    voxel_downsample_batch(d.ctx, d.voxMap, "map", n);
+
+    GridArgs g{};
+    for (int w = 0; w < 2; w++) { g.meta[w] = d.grid[w].meta; g.cell_start[w] = d.grid[w].cell_start; g.sorted[w] = d.grid[w].sorted; }
+    g.vox = d.voxMap.d_grid; g.nout = d.voxMap.d_nout;
+    g.ds[0] = d.mapCornerDS; g.ds[1] = d.mapSurfDS;
+    g.keysA = d.gridSort.keysA; g.valsA = d.gridSort.valsA; g.keysB = d.gridSort.keysB; g.valsB = d.gridSort.valsB;
+    g.d_n = d.d_grid_n; g.d_nbits = d.d_grid_nbits; g.cap = d.map_cap; g.max_cells = d.max_cells; g.d_status = d.d_status;
+    const double nds = 0.2 * n;      // nominal DS size for byte accounting only
+    const dim3 gp(div_up(d.map_cap, 256), 2);
+    LVI_LAUNCH(d.ctx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1), dim3(64), 0, d.ctx.stream, g));
+    LVI_LAUNCH(d.ctx, "grid_keys", 24.0 * nds, hipLaunchKernelGGL(grid_keys_kernel, gp, dim3(256), 0, d.ctx.stream, g));
+    radix_sort_pairs(d.ctx, d.gridSort, d.d_grid_n, d.d_grid_nbits, 3, "grid", nds);
+    LVI_LAUNCH(d.ctx, "grid_fill", 0, hipLaunchKernelGGL(grid_fill_kernel, dim3(2048, 2), dim3(256), 0, d.ctx.stream, g));
+    LVI_LAUNCH(d.ctx, "grid_gather", 36.0 * nds, hipLaunchKernelGGL(grid_gather_kernel, gp, dim3(256), 0, d.ctx.stream, g));
+}
+
+void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_imu_hint* imu, void* d_record)
+{
+    IcpArgs a = icp_args(d);
+    a.imu_available = imu ? imu->imu_available : 0;
+    a.imu_roll = imu ? imu->imu_roll_init : 0.f;
+    a.imu_pitch = imu ? imu->imu_pitch_init : 0.f;
+    a.d_record = d_record;
+    const double Q = 0.25 * d.n_raw;       // nominal query count for byte accounting only
+    LVI_LAUNCH(d.ctx, "icp_init", 0, hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a,
+                                                       pose_init[0], pose_init[1], pose_init[2], pose_init[3], pose_init[4], pose_init[5], d.have_map ? 1 : 0));
+    for (int it = 0; it < a.max_iters; it++) {
+        LVI_LAUNCH(d.ctx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL(icp_residual_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a));
+        LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, d.ctx.stream, a, it));
+    }
+    LVI_LAUNCH(d.ctx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a));
+}
+
+void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd)
+{
+    hipLaunchKernelGGL(knn_debug_kernel, dim3(div_up(std::max(nq, 1), 256)), dim3(256), 0, d.ctx.stream,
+                       d.grid[which].meta, d.grid[which].cell_start, d.grid[which].sorted, d_queries, nq, d_idx, d_sqd);
+    LVI_HIP(hipGetLastError());
+}
+
+void debug_residuals(LidarDev& d, int which, const float pose[6])
+{
+    IcpArgs a = icp_args(d);
+    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->pose, pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]);
+    hipLaunchKernelGGL(residual_debug_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a, which, &d.icp->pose);
+    LVI_HIP(hipGetLastError());
+}
+
+void transform_cloud(LidarDev& d, const lvi_pt* d_in, int n, const float pose6[6], lvi_pt* d_out)
+{
+    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->pose, pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5]);
+    LVI_LAUNCH(d.ctx, "transform_cloud", 32.0 * n, hipLaunchKernelGGL(transform_dev_pose_kernel, dim3(div_up(std::max(n, 1), 256)), dim3(256), 0, d.ctx.stream,
+                                                                     d_in, n, &d.icp->pose, d_out));
+}
+
+}  // namespace lvi

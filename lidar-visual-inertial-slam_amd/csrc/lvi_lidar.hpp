@@ -1,0 +1,101 @@
+// Device-resident state of one lidar handle and the stage launchers (implemented in
+// lvi_scan.hip and lvi_icp.hip; lvi_capi.hip wires them to the C-ABI).
+#pragma once
+#include "lvi_voxel.hpp"
+
+namespace lvi {
+
+constexpr int ORG_TILE = 1024;          // raw points per workgroup in the organise kernels
+constexpr int FEAT_SEG_CAP = 8192;      // max points of one ring sector held in LDS (+ halo)
+constexpr int MAX_N_SCAN = 32;
+constexpr int CORNERS_PER_SECTOR = 40;  // featureExtraction.cpp:180
+constexpr int ICP_BLOCK = 256;
+
+// device status bits (sticky until the next upload)
+enum { DEV_ERR_SECTOR_TOO_LARGE = 1, DEV_ERR_GRID_TOO_LARGE = 2 };
+
+struct IcpPose {                         // written by icp_solve for the next residual pass
+    float T[6];                          // transformTobeMapped: roll pitch yaw x y z
+    float A[12];                         // trans2Affine3f(T), row-major 3x4
+    float trig[6];                       // srx crx sry cry srz crz (LMOptimization :1202-1207)
+};
+
+struct IcpState {                        // device, one per handle
+    IcpPose pose;
+    int done;                            // LMOptimization returned true (and break enabled) or loop skipped
+    int converged, degenerate, iters, any_lm, status;
+    int n_sel[LVI_ICP_MAX_ITERS];
+    float jtj[LVI_ICP_MAX_ITERS * 27];
+    float pose_trace[(LVI_ICP_MAX_ITERS + 1) * 6];
+    lvi_pose_record record;              // final
+    float final_pose[6];
+};
+
+struct GridIndex {                       // uniform 1 m grid over one DS map (a-6 replacement for the kd-tree)
+    int* cell_start = nullptr;           // [max_cells + 1]
+    lvi_pt* sorted = nullptr;            // [cap] xyz + original DS index in the intensity slot (as int bits)
+    struct Meta { double origin[3]; int dim[3]; int ncells; int n; int ok; }* meta = nullptr;   // device
+};
+
+struct LidarDev {
+    lvi_lidar_params P;
+    int device = 0;
+    Ctx ctx;
+    Profiler prof;
+    Arena arena;
+
+    // capacities
+    int raw_cap = 0, ext_cap = 0, ring_cap = 0, map_cap = 0, nblk_org = 0, max_cells = 0;
+
+    // ---- a-0
+    lvi_livox_pt* raw = nullptr; int n_raw = 0;            // after dropping the last point
+    int* blockCnt = nullptr;                               // [N_SCAN][nblk_org]
+    int* ringBase = nullptr;                               // [N_SCAN + 1] (kept columns)
+    int *startR = nullptr, *endR = nullptr, *d_n = nullptr;
+    lvi_pt* pts = nullptr; float* range = nullptr; int* col = nullptr;
+    // ---- a-1..a-3
+    float* curv = nullptr; uint8_t *picked = nullptr, *picked_occl = nullptr, *surfmask = nullptr; int8_t* label = nullptr;
+    int *sector_idx = nullptr, *sector_cnt = nullptr;      // [N_SCAN*6*40], [N_SCAN*6]
+    lvi_pt* corner = nullptr; int* corner_idx = nullptr; int* d_ncorner = nullptr;
+    lvi_pt* surf = nullptr;                                // concatenated per-ring DS output
+    int* d_fresh = nullptr;                                // 1 until the first extract of this handle
+    int* d_status = nullptr;
+    VoxelPlan voxRing;                                     // N_SCAN segments, leaf odometrySurfLeafSize
+    // ---- scan DS
+    lvi_pt *cornerDS = nullptr, *surfDS = nullptr;
+    VoxelPlan voxScan;                                     // 2 segments (corner, surf)
+    // ---- map
+    lvi_pt *mapCornerRaw = nullptr, *mapSurfRaw = nullptr, *mapCornerDS = nullptr, *mapSurfDS = nullptr;
+    int n_map_corner = 0, n_map_surf = 0;
+    VoxelPlan voxMap;                                      // 2 segments
+    GridIndex grid[2];
+    SortPlan gridSort;                                     // 2 segments (corner, surf)
+    int *d_grid_n = nullptr, *d_grid_nbits = nullptr;
+    // ---- generic one-call voxel (lvi_voxel_downsample)
+    lvi_pt *genIn = nullptr, *genOut = nullptr;
+    VoxelPlan voxGen;                                      // 1 segment
+    unsigned* genKeysDbg = nullptr;
+    // ---- icp
+    IcpState* icp = nullptr;
+    double* icpPartial = nullptr;                          // [nblk_icp][28]
+    lvi_pt* coeff = nullptr; uint8_t* flag = nullptr;      // [ext_cap] corner queries first, then surf
+    int nblk_icp = 0;
+    IcpState* h_icp = nullptr;                             // pinned host mirror
+    // stage flags (host)
+    bool have_raw = false, have_org = false, have_feat = false, have_ds = false, have_map_raw = false, have_map = false;
+    bool gen_valid = false; int gen_n = 0;
+};
+
+// lvi_scan.hip
+void lidar_allocate(LidarDev& d);
+void stage_organize(LidarDev& d);
+void stage_extract(LidarDev& d);
+void stage_downsample(LidarDev& d);
+// lvi_icp.hip
+void stage_map_build(LidarDev& d);
+void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_imu_hint* imu, void* d_record);
+void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd);
+void debug_residuals(LidarDev& d, int which, const float pose[6]);
+void transform_cloud(LidarDev& d, const lvi_pt* d_in, int n, const float pose6[6], lvi_pt* d_out);
+
+}  // namespace lvi

@@ -1,0 +1,304 @@
+// pcl::VoxelGrid<PointXYZI>::applyFilter for gfx950.
+//
+// Per batch, all segments at once (blockIdx.y = segment), nothing returns to the host:
+//   vox_init → vox_minmax (bbox, order-encoded atomics) → vox_setup (grid dims, overflow rule,
+//   key width) → vox_keys (i32 voxel idx per point, exact PCL arithmetic, no FMA) →
+//   stable radix sort of (idx, point index) → vox_heads_* (ordered compaction of the first
+//   entry of every distinct idx) → vox_centroid (f32 running sums in sorted order, / count).
+// HBM-bound: algorithmic bytes 16·P read + 16·V written; the sort adds 20·P per 8-bit pass.
+#include "lvi_voxel.hpp"
+
+namespace lvi {
+
+namespace {
+
+struct VoxArgs {
+    const VoxSegStatic* st; const VoxSegDyn* dyn; VoxGrid* grid;
+    int *d_n, *d_nbits;
+    unsigned *keysA, *valsA, *keysB, *valsB;
+    int* blockHeads; int* starts; int* nout;
+    int nseg, seg_cap, nblk_h, concat;
+};
+
+__global__ void vox_init_kernel(VoxArgs a)
+{
+    const int s = threadIdx.x;
+    if (s >= a.nseg) return;
+    VoxGrid& g = a.grid[s];
+    g.bb[0] = g.bb[1] = g.bb[2] = 0xFFFFFFFFu;
+    g.bb[3] = g.bb[4] = g.bb[5] = 0u;
+    g.n_valid = 0;
+    int n = a.dyn[s].n;
+    if (n < 0) n = 0;
+    if (n > a.seg_cap) n = a.seg_cap;
+    a.d_n[s] = n;
+}
+
+__global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const int n = a.d_n[s];
+    const lvi_pt* __restrict__ in = a.st[s].in + a.dyn[s].in_off;
+    const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + a.dyn[s].in_off : nullptr;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int cnt = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (mask && !mask[i]) continue;
+        const lvi_pt p = in[i];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        cnt++;
+    }
+    cnt = wave_sum(cnt);
+    if (cnt == 0) return;                       // wave-uniform
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    if (lane_id() == 0) {
+        VoxGrid& g = a.grid[s];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { atomicMin(&g.bb[d], f2ord(mn[d])); atomicMax(&g.bb[3 + d], f2ord(mx[d])); }
+        atomicAdd(&g.n_valid, cnt);
+    }
+}
+
+__global__ void vox_setup_kernel(VoxArgs a)
+{
+    const int s = threadIdx.x;
+    if (s >= a.nseg) return;
+    VoxGrid& g = a.grid[s];
+    g.overflow = 0; g.nvox = 0; g.out_off = 0;
+    if (g.n_valid == 0) { g.sentinel = 0u; g.nbits = 0; a.d_nbits[s] = 0; g.inv = 0.f; return; }
+    const float leaf = a.st[s].leaf;
+    const float inv = div_rn(1.0f, leaf);
+    g.inv = inv;
+    float mnp[3], mxp[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mnp[d] = ord2f(g.bb[d]); mxp[d] = ord2f(g.bb[3 + d]); }
+    // dx = static_cast<int64>((max-min)*inv) + 1 … ; dx*dy*dz > INT32_MAX.  Evaluated in double (exact for
+    // every product that can pass the test; hipcc 7.2 crashes in isel on the f32→i64 form of this kernel).
+    const double dx = trunc((double)mul_rn(sub_rn(mxp[0], mnp[0]), inv)) + 1.0;
+    const double dy = trunc((double)mul_rn(sub_rn(mxp[1], mnp[1]), inv)) + 1.0;
+    const double dz = trunc((double)mul_rn(sub_rn(mxp[2], mnp[2]), inv)) + 1.0;
+    if (!(dx * dy * dz <= 2147483647.0)) {
+        // "Leaf size is too small for the input dataset. Integer indices would overflow." → output = input.
+        // Realised as one voxel per point: key = point index (already ascending, sort is a no-op permutation).
+        g.overflow = 1;
+        g.sentinel = (unsigned)a.seg_cap;
+        g.nbits = 32 - __clz((unsigned)a.seg_cap);
+        a.d_nbits[s] = g.nbits;
+        return;
+    }
+    int maxb[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        g.min_b[d] = (int)floorf(mul_rn(mnp[d], inv));
+        maxb[d] = (int)floorf(mul_rn(mxp[d], inv));
+        g.div_b[d] = maxb[d] - g.min_b[d] + 1;
+    }
+    g.mul1 = (unsigned)g.div_b[0];
+    g.mul2 = (unsigned)g.div_b[0] * (unsigned)g.div_b[1];
+    const unsigned long long ncells = (unsigned long long)g.div_b[0] * (unsigned long long)g.div_b[1] * (unsigned long long)g.div_b[2];
+    if (ncells >= 0xFFFFFFFFull) { g.sentinel = 0xFFFFFFFFu; g.nbits = 32; }
+    else {
+        g.sentinel = (unsigned)ncells;
+        int nb = 0;
+        for (unsigned long long t = ncells; t; t >>= 1) nb++;
+        g.nbits = nb;
+    }
+    a.d_nbits[s] = g.nbits;
+}
+
+__global__ __launch_bounds__(256) void vox_keys_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const int n = a.d_n[s];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const VoxGrid& g = a.grid[s];
+    const int off = a.dyn[s].in_off;
+    const uint8_t* mask = a.st[s].mask;
+    unsigned key;
+    if (mask && !mask[off + i]) {
+        key = g.sentinel;
+    } else if (g.overflow) {
+        key = (unsigned)i;
+    } else {
+        const lvi_pt p = a.st[s].in[off + i];
+        const int ijk0 = (int)sub_rn(floorf(mul_rn(p.x, g.inv)), (float)g.min_b[0]);
+        const int ijk1 = (int)sub_rn(floorf(mul_rn(p.y, g.inv)), (float)g.min_b[1]);
+        const int ijk2 = (int)sub_rn(floorf(mul_rn(p.z, g.inv)), (float)g.min_b[2]);
+        key = (unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2;
+    }
+    const size_t o = (size_t)s * a.seg_cap + i;
+    a.keysA[o] = key;
+    a.valsA[o] = (unsigned)i;
+}
+
+__device__ __forceinline__ const unsigned* sorted_keys(const VoxArgs& a, int s)
+{
+    return (rs_result_in_B(a.d_nbits[s]) ? a.keysB : a.keysA) + (size_t)s * a.seg_cap;
+}
+__device__ __forceinline__ const unsigned* sorted_vals(const VoxArgs& a, int s)
+{
+    return (rs_result_in_B(a.d_nbits[s]) ? a.valsB : a.valsA) + (size_t)s * a.seg_cap;
+}
+
+__device__ __forceinline__ bool is_head(const unsigned* keys, int i, unsigned sentinel)
+{
+    const unsigned k = keys[i];
+    return k != sentinel && (i == 0 || keys[i - 1] != k);
+}
+
+__global__ __launch_bounds__(256) void vox_heads_count_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const int n = a.d_n[s];
+    const int base = blockIdx.x * VOX_HT;
+    if (base >= n) return;
+    const unsigned* keys = sorted_keys(a, s);
+    const unsigned sent = a.grid[s].sentinel;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int i = base + threadIdx.x * 4 + j; if (i < n && is_head(keys, i, sent)) c++; }
+    __shared__ int ws[8];
+    int tot;
+    block_excl_scan<256>(c, ws, &tot);
+    if (threadIdx.x == 0) a.blockHeads[s * a.nblk_h + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void vox_heads_scan_kernel(VoxArgs a)
+{
+    __shared__ int ws[8];
+    for (int s = 0; s < a.nseg; s++) {
+        const int n = a.d_n[s];
+        const int nt = (n + VOX_HT - 1) / VOX_HT;
+        int* row = a.blockHeads + s * a.nblk_h;
+        int carry = 0;
+        for (int c = 0; c < nt; c += 256) {
+            const int i = c + threadIdx.x;
+            const int v = (i < nt) ? row[i] : 0;
+            int tot;
+            const int ex = block_excl_scan<256>(v, ws, &tot);
+            if (i < nt) row[i] = carry + ex;
+            carry += tot;
+        }
+        if (threadIdx.x == 0) a.grid[s].nvox = carry;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int s = 0; s < a.nseg; s++) {
+            a.grid[s].out_off = a.concat ? off : 0;
+            a.nout[s] = a.grid[s].nvox;
+            off += a.grid[s].nvox;
+        }
+        a.nout[a.nseg] = off;
+    }
+}
+
+__global__ __launch_bounds__(256) void vox_heads_assign_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const int n = a.d_n[s];
+    const int base = blockIdx.x * VOX_HT;
+    if (base >= n) return;
+    const unsigned* keys = sorted_keys(a, s);
+    const unsigned sent = a.grid[s].sentinel;
+    int* starts = a.starts + (size_t)s * ((size_t)a.seg_cap + 1);
+    const int nvox = a.grid[s].nvox;
+    bool h[4]; int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int i = base + threadIdx.x * 4 + j; h[j] = (i < n) && is_head(keys, i, sent); c += h[j]; }
+    __shared__ int ws[8];
+    int v = a.blockHeads[s * a.nblk_h + blockIdx.x] + block_excl_scan<256>(c, ws, nullptr);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = base + threadIdx.x * 4 + j;
+        if (i >= n) break;
+        if (h[j]) starts[v++] = i;
+        // end of the last voxel = first sentinel entry, or n
+        const unsigned k = keys[i];
+        if (k == sent) { if (i == 0 || keys[i - 1] != sent) starts[nvox] = i; }
+        else if (i == n - 1) starts[nvox] = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void vox_centroid_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const VoxGrid& g = a.grid[s];
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= g.nvox) return;
+    const int* starts = a.starts + (size_t)s * ((size_t)a.seg_cap + 1);
+    const unsigned* vals = sorted_vals(a, s);
+    const lvi_pt* __restrict__ in = a.st[s].in + a.dyn[s].in_off;
+    const int b = starts[v], e = starts[v + 1];
+    // pcl::CentroidPoint: f32 running sums in sorted order, divided by the count
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    for (int j = b; j < e; j++) {
+        const lvi_pt p = in[vals[j]];
+        sx = add_rn(sx, p.x); sy = add_rn(sy, p.y); sz = add_rn(sz, p.z); si = add_rn(si, p.intensity);
+    }
+    const float cnt = (float)(e - b);
+    lvi_pt o;
+    o.x = div_rn(sx, cnt); o.y = div_rn(sy, cnt); o.z = div_rn(sz, cnt); o.intensity = div_rn(si, cnt);
+    lvi_pt* out = a.concat ? a.st[0].out : a.st[s].out;
+    out[g.out_off + v] = o;
+}
+
+}  // namespace
+
+void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs) const
+{
+    LVI_HIP(hipMemcpyAsync(d_static, host_segs, sizeof(VoxSegStatic) * nseg, hipMemcpyHostToDevice, ctx.stream));
+    LVI_HIP(hipStreamSynchronize(ctx.stream));
+}
+
+// Debug view of segment 0 of the last run (tests only): per-input-point keys, distinct keys in
+// output order and points per output voxel.  Overflow-rule runs report empty arrays.
+void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector<int32_t>& keys, std::vector<int32_t>& cells, std::vector<int32_t>& counts)
+{
+    keys.clear(); cells.clear(); counts.clear();
+    VoxGrid g;
+    LVI_HIP(hipMemcpyAsync(&g, p.d_grid, sizeof(g), hipMemcpyDeviceToHost, ctx.stream));
+    LVI_HIP(hipStreamSynchronize(ctx.stream));
+    if (g.overflow || n_in <= 0 || g.n_valid == 0) return;
+    const bool inB = (((g.nbits + 7) >> 3) & 1) != 0;
+    std::vector<unsigned> sk(n_in);
+    std::vector<int> st(g.nvox + 1);
+    LVI_HIP(hipMemcpyAsync(sk.data(), inB ? p.sort.keysB : p.sort.keysA, sizeof(unsigned) * n_in, hipMemcpyDeviceToHost, ctx.stream));
+    LVI_HIP(hipMemcpyAsync(st.data(), p.d_starts, sizeof(int) * (g.nvox + 1), hipMemcpyDeviceToHost, ctx.stream));
+    LVI_HIP(hipStreamSynchronize(ctx.stream));
+    cells.resize(g.nvox); counts.resize(g.nvox);
+    for (int v = 0; v < g.nvox; v++) { cells[v] = (int32_t)sk[st[v]]; counts[v] = st[v + 1] - st[v]; }
+    // per-point keys: recompute into keysA (scratch is free once the outputs are written)
+    VoxArgs a{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
+              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0};
+    hipLaunchKernelGGL(vox_keys_kernel, dim3(div_up(n_in, 256), 1), dim3(256), 0, ctx.stream, a);
+    LVI_HIP(hipGetLastError());
+    keys.resize(n_in);
+    LVI_HIP(hipMemcpyAsync(keys.data(), p.sort.keysA, sizeof(unsigned) * n_in, hipMemcpyDeviceToHost, ctx.stream));
+    LVI_HIP(hipStreamSynchronize(ctx.stream));
+}
+
+void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
+{
+    VoxArgs a{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
+              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0};
+    char nm[8][48];
+    const char* base[8] = {"vox_init", "vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid"};
+    for (int i = 0; i < 8; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
+    const int mm_blocks = std::max(1, std::min(div_up(p.seg_cap, 256 * 4), 2048));
+    const dim3 gp(div_up(p.seg_cap, 256), p.nseg), gh(p.nblk_h, p.nseg);
+    LVI_LAUNCH(ctx, nm[0], 0, hipLaunchKernelGGL(vox_init_kernel, dim3(1), dim3(64), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[1], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(mm_blocks, p.nseg), dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[2], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(1), dim3(64), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[3], 24.0 * n_hint, hipLaunchKernelGGL(vox_keys_kernel, gp, dim3(256), 0, ctx.stream, a));
+    radix_sort_pairs(ctx, p.sort, p.d_n, p.d_nbits, 4, tag, n_hint);
+    LVI_LAUNCH(ctx, nm[4], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_count_kernel, gh, dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[5], 0, hipLaunchKernelGGL(vox_heads_scan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[6], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_assign_kernel, gh, dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[7], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel, gp, dim3(256), 0, ctx.stream, a));
+}
+
+}  // namespace lvi

@@ -1,0 +1,327 @@
+"""GPU tier (-m gpu): the HIP lidar path against the CPU oracle through the same C-ABI.
+
+Bar (BASELINE.json north_star): point indices / voxel keys / column indices bit-exact;
+f32 values that follow a fixed operation order bit-exact; voxel centroids within
+count * 2^-23 * max|coord| (PCL's sum order inside a voxel is unspecified); pose within
+1e-4 m / 1e-4 rad.  PARITY UNPINNED: the oracle restates the reference, which ships no
+golden vectors (see oracle/ headers)."""
+import numpy as np
+import pytest
+
+from helpers import bits, centroid_tol, make_small_scene, small_params, xyzi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(pkg, oracle):
+    return make_small_scene(pkg, oracle)
+
+
+@pytest.fixture()
+def pair(pkg, oracle, hip):
+    o = pkg.LidarHotpath(oracle, **small_params())
+    g = pkg.LidarHotpath(hip, **small_params())
+    yield o, g
+    o.close(); g.close()
+
+
+def _assert_info_equal(a, b):
+    assert a["n"] == b["n"]
+    np.testing.assert_array_equal(a["start_ring_index"], b["start_ring_index"])
+    np.testing.assert_array_equal(a["end_ring_index"], b["end_ring_index"])
+    np.testing.assert_array_equal(a["point_col_ind"], b["point_col_ind"])
+    np.testing.assert_array_equal(bits(a["point_range"]), bits(b["point_range"]))
+    np.testing.assert_array_equal(xyzi(a["cloud_deskewed"]).view(np.uint32), xyzi(b["cloud_deskewed"]).view(np.uint32))
+
+
+# ----------------------------------------------------------------------------- a-0
+def test_organize_bit_exact(pair, scene):
+    o, g = pair
+    _assert_info_equal(o.organize_scan(scene["scan"]), g.organize_scan(scene["scan"]))
+
+
+def test_organize_edge_cases(pkg, oracle, hip):
+    A = pkg._abi
+    rng = np.random.default_rng(5)
+    # tiny Horizon: columns past Horizon_SCAN are dropped; lines >= N_SCAN and out-of-range points are gated
+    kw = dict(N_SCAN=4, Horizon_SCAN=100, max_raw_points=4096, max_map_points=1024)
+    o = pkg.LidarHotpath(oracle, **kw); g = pkg.LidarHotpath(hip, **kw)
+    pts = np.zeros(3001, A.LIVOX_DTYPE)
+    pts["x"] = rng.uniform(-60, 60, 3001); pts["y"] = rng.uniform(-60, 60, 3001); pts["z"] = rng.uniform(-2, 5, 3001)
+    pts["x"][::17] = 0.1; pts["y"][::17] = 0.1; pts["z"][::17] = 0.1          # below lidarMinRange
+    pts["x"][5::23] = 500.0                                                   # beyond lidarMaxRange
+    pts["line"] = rng.integers(0, 6, 3001)                                    # 4,5 are outside N_SCAN
+    pts["reflectivity"] = rng.integers(0, 256, 3001)
+    _assert_info_equal(o.organize_scan(pts), g.organize_scan(pts))
+    for n in (0, 1, 2, 7):
+        _assert_info_equal(o.organize_scan(pts[:n]), g.organize_scan(pts[:n]))
+    # the final point of the message is dropped (imageProjection.cpp:249)
+    one = pts[:2].copy(); one["x"] = 5; one["y"] = 0; one["z"] = 0; one["line"] = 0
+    assert g.organize_scan(one)["n"] == 1
+    o.close(); g.close()
+
+
+# ----------------------------------------------------------------------------- a-1..a-3
+def test_smoothness_and_occlusion_bit_exact(pkg, pair, scene):
+    A = pkg._abi
+    o, g = pair
+    for h in (o, g):
+        h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract()
+    n = o.counts()["n"]
+    co, cg = o.debug_get(A.DBG_CURVATURE, np.float32), g.debug_get(A.DBG_CURVATURE, np.float32)
+    np.testing.assert_array_equal(bits(co[5:n - 5]), bits(cg[5:n - 5]))
+    po, pg = o.debug_get(A.DBG_PICKED_OCCL, np.int32), g.debug_get(A.DBG_PICKED_OCCL, np.int32)
+    np.testing.assert_array_equal(po[5:n - 5], pg[5:n - 5])
+
+
+def test_feature_extraction_indices_bit_exact(pkg, pair, scene):
+    A = pkg._abi
+    o, g = pair
+    for h in (o, g):
+        h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract()
+    io, ig = o.debug_get(A.DBG_CORNER_INDEX, np.int32), g.debug_get(A.DBG_CORNER_INDEX, np.int32)
+    assert len(io) > 50, "scene should produce corners"
+    np.testing.assert_array_equal(io, ig)
+    n = o.counts()["n"]
+    lo, lg = o.debug_get(A.DBG_LABEL, np.int32), g.debug_get(A.DBG_LABEL, np.int32)
+    np.testing.assert_array_equal(lo[5:n - 5], lg[5:n - 5])
+    fo, fg = o.debug_get(A.DBG_PICKED_FINAL, np.int32), g.debug_get(A.DBG_PICKED_FINAL, np.int32)
+    np.testing.assert_array_equal(fo[5:n - 6], fg[5:n - 6])
+    (c_o, s_o), (c_g, s_g) = o.get_features(), g.get_features()
+    np.testing.assert_array_equal(xyzi(c_o).view(np.uint32), xyzi(c_g).view(np.uint32))
+    assert len(s_o) == len(s_g)
+    np.testing.assert_allclose(xyzi(s_o), xyzi(s_g), rtol=0, atol=2e-5)
+
+
+def test_second_scan_on_same_handle(pkg, pair, scene):
+    """state that survives a scan must not change results vs the oracle"""
+    A = pkg._abi
+    o, g = pair
+    S = pkg.synth
+    scan2 = S.make_scan(20001, S.loop_pose(1.1, -0.01, 0.02), 999)
+    for h in (o, g):
+        for sc in (scene["scan"], scan2):
+            h.scan_upload(sc); h.scan_organize(); h.scan_extract()
+    np.testing.assert_array_equal(o.debug_get(A.DBG_CORNER_INDEX, np.int32), g.debug_get(A.DBG_CORNER_INDEX, np.int32))
+    assert o.counts() == g.counts()
+
+
+def test_extract_features_one_call_seam(pair, scene):
+    o, g = pair
+    info = o.organize_scan(scene["scan"])
+    (c_o, s_o), (c_g, s_g) = o.extract_features(info), g.extract_features(info)
+    np.testing.assert_array_equal(xyzi(c_o).view(np.uint32), xyzi(c_g).view(np.uint32))
+    assert len(s_o) == len(s_g)
+    np.testing.assert_allclose(xyzi(s_o), xyzi(s_g), rtol=0, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- a-4
+def _voxel_case(pkg, o, g, pts, leaf):
+    A = pkg._abi
+    vo, vg = o.voxel_downsample(pts, leaf), g.voxel_downsample(pts, leaf)
+    ko, kg = o.debug_get(A.DBG_VOXEL_KEYS, np.int32), g.debug_get(A.DBG_VOXEL_KEYS, np.int32)
+    np.testing.assert_array_equal(ko, kg)
+    np.testing.assert_array_equal(o.debug_get(A.DBG_VOXEL_CELLS, np.int32), g.debug_get(A.DBG_VOXEL_CELLS, np.int32))
+    cnt = o.debug_get(A.DBG_VOXEL_COUNTS, np.int32)
+    np.testing.assert_array_equal(cnt, g.debug_get(A.DBG_VOXEL_COUNTS, np.int32))
+    assert len(vo) == len(vg)
+    if len(vo):
+        assert np.all(np.abs(xyzi(vo).astype(np.float64) - xyzi(vg)) <= centroid_tol(cnt, vo))
+    return len(vo)
+
+
+def test_voxel_downsample_keys_bit_exact(pkg, pair):
+    o, g = pair
+    rng = np.random.default_rng(1)
+    pts = np.zeros((30000, 4), np.float32)
+    pts[:, :3] = rng.uniform(-40, 40, (30000, 3)) * [1, 1, 0.1]
+    pts[:, 3] = rng.uniform(0, 255, 30000)
+    for leaf in (0.4, 0.2, 1.0, 0.05):
+        assert _voxel_case(pkg, o, g, pts, leaf) > 100
+    # clustered (many points per voxel), negative-only and positive-only coordinates
+    c = np.zeros((5000, 4), np.float32); c[:, :3] = rng.normal(0, 0.3, (5000, 3)) + [-7.3, 2.2, -1.1]
+    _voxel_case(pkg, o, g, c, 0.4)
+    _voxel_case(pkg, o, g, np.abs(c), 0.2)
+    _voxel_case(pkg, o, g, -np.abs(c), 0.2)
+
+
+def test_voxel_downsample_edge_cases(pkg, pair):
+    o, g = pair
+    assert len(g.voxel_downsample(np.zeros((0, 4), np.float32), 0.4)) == 0
+    one = np.array([[1.5, -2.5, 0.25, 7.0]], np.float32)
+    np.testing.assert_array_equal(xyzi(g.voxel_downsample(one, 0.4)), one)
+    same = np.repeat(one, 100, axis=0)
+    r = xyzi(g.voxel_downsample(same, 0.4))
+    assert r.shape == (1, 4) and np.allclose(r, one, atol=1e-5)
+    # PCL overflow rule: dx*dy*dz > INT32_MAX -> output is the input, unchanged and in order
+    far = np.array([[0, 0, 0, 1], [3000, 3000, 3000, 2], [1, 1, 1, 3], [-3000, 10, 10, 4]], np.float32)
+    ro, rg = o.voxel_downsample(far, 0.01), g.voxel_downsample(far, 0.01)
+    np.testing.assert_array_equal(xyzi(ro), far)
+    np.testing.assert_array_equal(xyzi(rg), far)
+
+
+# ----------------------------------------------------------------------------- a-5
+def test_transform_cloud(pair, scene):
+    o, g = pair
+    pts = scene["map_surf"][:5000]
+    pose = [0.02, -0.03, 1.2, 3.0, -4.0, 0.5]
+    np.testing.assert_allclose(xyzi(o.transform_cloud(pts, pose)), xyzi(g.transform_cloud(pts, pose)), rtol=0, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- a-4(map) + a-6
+def test_map_build_and_knn_exact(pkg, pair, scene):
+    o, g = pair
+    for h in (o, g):
+        h.map_set(scene["map_corner"], scene["map_surf"])
+    co, cg = o.counts(), g.counts()
+    assert co["map_corner_ds"] == cg["map_corner_ds"] and co["map_surf_ds"] == cg["map_surf_ds"]
+    (mco, mso), (mcg, msg) = o.get_map_ds(), g.get_map_ds()
+    np.testing.assert_allclose(xyzi(mco), xyzi(mcg), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(xyzi(mso), xyzi(msg), rtol=0, atol=5e-5)
+    # queries: map points jittered (dense neighbourhoods) + far-away points (rejected)
+    rng = np.random.default_rng(3)
+    for which, m in ((0, mcg), (1, msg)):
+        # give the oracle exactly the GPU's DS map so that index parity is meaningful
+        q = xyzi(m)[rng.integers(0, len(m), 4000)].copy()
+        q[:, :3] += rng.normal(0, 0.15, (4000, 3)).astype(np.float32)
+        q[-200:, :3] += 50.0
+        io, do = o.debug_knn(which, q)
+        ig, dg = g.debug_knn(which, q)
+        accepted = io[:, 4] >= 0
+        assert accepted.sum() > 500
+        # maps can differ in the last bit of a centroid; distances then differ by rounding, indices must not
+        mism = (io != ig).any(axis=1)
+        assert mism.mean() < 2e-3, f"{mism.sum()} of {len(q)} queries differ"
+        np.testing.assert_allclose(do[~mism], dg[~mism], rtol=1e-4, atol=1e-6)
+
+
+def test_knn_index_bit_exact_on_identical_map(pkg, oracle, hip):
+    """integer-valued map coordinates → both voxel paths give identical centroids → KNN must match exactly"""
+    rng = np.random.default_rng(11)
+    P = small_params()
+    o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P)
+    m = np.zeros((60000, 4), np.float32)
+    m[:, :3] = (rng.integers(-200, 200, (60000, 3)) * 0.25 + 0.125) * [1, 1, 0.2]      # one point per 0.2-voxel at most twice
+    m = np.unique(m, axis=0)
+    for h in (o, g):
+        h.map_set(m, m)
+    (mco, mso), (mcg, msg) = o.get_map_ds(), g.get_map_ds()
+    np.testing.assert_array_equal(xyzi(mco), xyzi(mcg))
+    np.testing.assert_array_equal(xyzi(mso), xyzi(msg))
+    q = np.zeros((6000, 4), np.float32)
+    q[:, :3] = rng.uniform(-50, 50, (6000, 3)) * [1, 1, 0.2] + rng.normal(0, 1e-3, (6000, 3))
+    for which in (0, 1):
+        io, do = o.debug_knn(which, q)
+        ig, dg = g.debug_knn(which, q)
+        ties = np.array([len(np.unique(r[np.isfinite(r)])) < np.isfinite(r).sum() for r in do])
+        ok = ~ties
+        np.testing.assert_array_equal(io[ok], ig[ok])
+        np.testing.assert_array_equal(bits(do[ok]), bits(dg[ok]))
+    o.close(); g.close()
+
+
+# ----------------------------------------------------------------------------- a-7, a-8
+def test_residuals_at_fixed_pose(pkg, pair, scene):
+    o, g = pair
+    for h in (o, g):
+        h.map_set(scene["map_corner"], scene["map_surf"])
+        h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+    assert o.counts() == g.counts()
+    for which in (0, 1):
+        co, fo = o.debug_residuals(which, scene["guess"])
+        cg, fg = g.debug_residuals(which, scene["guess"])
+        assert fo.sum() > (20 if which == 0 else 1000)
+        both = (fo == 1) & (fg == 1)
+        assert (fo != fg).mean() < 5e-3, f"flag mismatch {(fo != fg).sum()} / {len(fo)}"
+        d = np.abs(xyzi(co)[both] - xyzi(cg)[both])
+        assert np.quantile(d, 0.999) < 2e-3 and np.median(d) < 1e-5, (np.quantile(d, 0.999), np.median(d))
+
+
+# ----------------------------------------------------------------------------- a-9, a-10
+def test_scan_to_map_pose_parity(pkg, pair, scene):
+    A = pkg._abi
+    o, g = pair
+    for h in (o, g):
+        h.map_set(scene["map_corner"], scene["map_surf"])
+        h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+    ro, rg = o.scan_match(scene["guess"]), g.scan_match(scene["guess"])
+    assert ro["status"] == 0 and rg["status"] == 0
+    assert ro["converged"] and rg["converged"]
+    assert ro["degenerate"] == rg["degenerate"]
+    assert ro["iters"] == rg["iters"]
+    assert max(abs(a - b) for a, b in zip(ro["n_sel"], rg["n_sel"])) <= 3
+    dp = np.abs(ro["pose"] - rg["pose"])
+    assert dp[:3].max() < 1e-4 and dp[3:].max() < 1e-4, dp
+    # and both land on the ground truth up to sensor noise
+    assert np.abs(rg["pose"][3:] - scene["pose"][3:]).max() < 0.03
+    assert np.abs(rg["pose"][:3] - scene["pose"][:3]).max() < 0.003
+    jo, jg = o.debug_get(A.DBG_ICP_JTJ, np.float32), g.debug_get(A.DBG_ICP_JTJ, np.float32)
+    np.testing.assert_allclose(jo[:27], jg[:27], rtol=2e-3, atol=1e-2)
+    # IMU hint path (transformUpdate slerp) and the one-call seam
+    imu = dict(imu_available=1, roll=0.012, pitch=-0.018, yaw=0.0)
+    c, s = o.get_features()
+    r2o = o.scan_to_map(c, s, scene["guess"], imu)
+    r2g = g.scan_to_map(c, s, scene["guess"], imu)
+    assert np.abs(r2o["pose"] - r2g["pose"]).max() < 1e-4
+
+
+def test_scan_match_soft_outcomes(pkg, pair, scene):
+    A = pkg._abi
+    o, g = pair
+    for h in (o, g):
+        h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+        assert h.scan_match(scene["guess"])["status"] == A.LVI_NO_MAP
+    # a map far away from the scan: no correspondences -> LMOptimization never runs
+    far_c = scene["map_corner"].copy(); far_s = scene["map_surf"].copy()
+    far_c["x"] += 500; far_s["x"] += 500
+    for h in (o, g):
+        h.map_set(far_c, far_s)
+        r = h.scan_match(scene["guess"])
+        assert r["status"] == A.LVI_TOO_FEW_CORRESPONDENCES and r["iters"] == 20 and max(r["n_sel"]) < 50
+        np.testing.assert_allclose(r["pose"], scene["guess"], atol=1e-6)
+    # too few features
+    few = scene["map_corner"][:5]
+    for h in (o, g):
+        r = h.scan_to_map(few, few, scene["guess"])
+        assert r["status"] == A.LVI_TOO_FEW_FEATURES
+
+
+def test_fixed_iteration_mode(pkg, oracle, hip, scene):
+    """throughput runs disable the convergence break on CPU and GPU alike (SURVEY §8 d)"""
+    P = small_params(icp_max_iters=10, icp_disable_break=1)
+    o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P)
+    for h in (o, g):
+        h.map_set(scene["map_corner"], scene["map_surf"])
+        h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+    ro, rg = o.scan_match(scene["guess"]), g.scan_match(scene["guess"])
+    assert ro["iters"] == 10 and rg["iters"] == 10
+    assert np.abs(ro["pose"] - rg["pose"]).max() < 1e-4
+    o.close(); g.close()
+
+
+# ----------------------------------------------------------------------------- full size
+def test_full_size_scan_properties(pkg, oracle, hip):
+    """BASELINE config sizes: 100k-pt scan; size-independent properties + oracle on the scan stages"""
+    A = pkg._abi
+    S = pkg.synth
+    P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=1 << 20)
+    o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P)
+    scan = S.make_scan(100001, S.loop_pose(2.2, 0.01, 0.0), 12345)
+    for h in (o, g):
+        h.scan_upload(scan); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+    assert o.counts() == g.counts()
+    np.testing.assert_array_equal(o.debug_get(A.DBG_CORNER_INDEX, np.int32), g.debug_get(A.DBG_CORNER_INDEX, np.int32))
+    info = g.get_scan_info()
+    assert info["n"] == 100000
+    # columns are a dense per-ring counter; ranges are inside the gate
+    for r in range(4):
+        b = info["start_ring_index"][r] - 4
+        e = info["end_ring_index"][r] + 6
+        np.testing.assert_array_equal(info["point_col_ind"][b:e], np.arange(e - b))
+    assert info["point_range"].min() >= 1.0 and info["point_range"].max() <= 100.0
+    # voxel idempotence: downsampling an already downsampled cloud with the same leaf keeps the count
+    cds, sds = g.get_scan_ds()
+    again = g.voxel_downsample(sds, 0.4)
+    assert abs(len(again) - len(sds)) <= 0.02 * len(sds)
+    o.close(); g.close()
