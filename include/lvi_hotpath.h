@@ -188,6 +188,11 @@ int32_t lvi_scan_match(lvi_lidar *h, const lvi_imu_hint *imu, float pose[6], lvi
  * (d_record: device pointer, e.g. a slot of the buffer RCCL all-gathers); no host sync. */
 int32_t lvi_scan_match_async(lvi_lidar *h, const float pose_init[6], void *d_record);
 
+/* [hip only] the same uploads from buffers that are already in HBM (device pointers on the
+ * handle's GPU, e.g. the tensors a replay harness keeps resident); device-to-device, no host sync. */
+int32_t lvi_scan_upload_device(lvi_lidar *h, const void *d_pts, int32_t n_raw);
+int32_t lvi_map_upload_device(lvi_lidar *h, const void *d_corner_raw, int32_t nc, const void *d_surf_raw, int32_t ns);
+
 /* fetch current stage outputs (host buffers) */
 int32_t lvi_get_scan_info(lvi_lidar *h, lvi_scan_info *out);
 int32_t lvi_get_features(lvi_lidar *h, lvi_cloud *corner, lvi_cloud *surf);       /* cornerCloud, surfaceCloud */

@@ -103,6 +103,8 @@ SIGNATURES = {
     "lvi_map_build": (_i32, [_vp]),
     "lvi_scan_match": (_i32, [_vp, _P(ImuHint), _P(_f32), _P(IcpResult)]),
     "lvi_scan_match_async": (_i32, [_vp, _P(_f32), _vp]),
+    "lvi_scan_upload_device": (_i32, [_vp, _vp, _i32]),
+    "lvi_map_upload_device": (_i32, [_vp, _vp, _i32, _vp, _i32]),
     "lvi_get_scan_info": (_i32, [_vp, _P(ScanInfo)]),
     "lvi_get_features": (_i32, [_vp, _P(Cloud), _P(Cloud)]),
     "lvi_get_scan_ds": (_i32, [_vp, _P(Cloud), _P(Cloud)]),

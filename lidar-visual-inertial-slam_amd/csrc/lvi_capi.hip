@@ -217,6 +217,31 @@ int32_t lvi_scan_upload(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw)
         return LVI_OK;
     });
 }
+int32_t lvi_scan_upload_device(lvi_lidar* h, const void* d_pts, int32_t n_raw)
+{
+    if (!h || (n_raw > 0 && !d_pts)) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (n_raw > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        d.n_raw = n_raw > 0 ? n_raw - 1 : 0;
+        if (d.n_raw) LVI_HIP(hipMemcpyAsync(d.raw, d_pts, sizeof(lvi_livox_pt) * (size_t)d.n_raw, hipMemcpyDeviceToDevice, d.ctx.stream));
+        LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
+        d.have_raw = true; d.have_org = d.have_feat = d.have_ds = false;
+        return LVI_OK;
+    });
+}
+int32_t lvi_map_upload_device(lvi_lidar* h, const void* c, int32_t nc, const void* s, int32_t ns)
+{
+    if (!h || nc < 0 || ns < 0 || (nc > 0 && !c) || (ns > 0 && !s)) return fail(LVI_ERR_INVALID_ARG, "bad map arguments");
+    if (nc > h->d.map_cap || ns > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        if (nc) LVI_HIP(hipMemcpyAsync(d.mapCornerRaw, c, sizeof(lvi_pt) * (size_t)nc, hipMemcpyDeviceToDevice, d.ctx.stream));
+        if (ns) LVI_HIP(hipMemcpyAsync(d.mapSurfRaw, s, sizeof(lvi_pt) * (size_t)ns, hipMemcpyDeviceToDevice, d.ctx.stream));
+        d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.have_map = false;
+        return LVI_OK;
+    });
+}
 int32_t lvi_scan_organize(lvi_lidar* h)
 {
     if (!h || !h->d.have_raw) return fail(LVI_ERR_STATE, "no scan uploaded");

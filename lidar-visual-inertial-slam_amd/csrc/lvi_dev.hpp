@@ -159,13 +159,16 @@ __device__ __forceinline__ int block_excl_scan(int v, int* ws, int* total)
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-// f32 arithmetic that must match the CPU restatement bit for bit: never contracted into FMA.
-// (The library is also compiled with -ffp-contract=off; these make the intent explicit.)
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
-__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
-__device__ __forceinline__ float sqrt_rn(float a) { return __fsqrt_rn(a); }
+// f32 arithmetic that must match the CPU restatement bit for bit.  On ROCm 7.2 the CUDA-style
+// __fmul_rn/__fadd_rn are plain operators and __fsqrt_rn is the NATIVE (1-ulp) square root, so
+// none of them gives any guarantee: exactness comes from compiling the library with
+// -ffp-contract=off (no FMA contraction; plain * + - are then IEEE round-to-nearest) and from
+// sqrtf() and '/' being correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+__device__ __forceinline__ float div_rn(float a, float b) { return a / b; }
+__device__ __forceinline__ float sqrt_rn(float a) { return sqrtf(a); }
 #endif  // __HIPCC__
 
 }  // namespace lvi

@@ -1,7 +1,509 @@
-// placeholder until the tracker kernels land (next commit): the symbols exist, compute fails loudly
-#include "lvi_dev.hpp"
-namespace { int32_t nyi() { lvi::set_error("tracker HIP path not built yet"); return LVI_ERR_UNSUPPORTED; } }
+// feature_tracker hot path for gfx950 behind the C-ABI:
+//   cv::calcOpticalFlowPyrLK(cur, forw, pts, …, Size(21,21), 3)   feature_tracker.cpp:113
+//   cv::goodFeaturesToTrack(forw, n_pts, N, 0.01, MIN_DIST, mask)  feature_tracker.cpp:166
+//
+// LK: the pyramids of the two resident images are built once per image (pyrDown, integer exact).
+// One wavefront per feature walks the levels top→0 inside ONE launch: the 24x24 source tile of the
+// previous level is staged in LDS, Scharr derivatives are formed on the fly for that tile only
+// (OpenCV differentiates the whole level), the 21x21 patch and its gradient live in registers
+// (7 pixels per lane), and every Newton step re-stages the 22x22 target tile and reduces the two
+// mismatch sums across the wave.  All patch arithmetic is OpenCV's fixed point (W_BITS = 14) with
+// exact int64 sums (the aarch64 build of OpenCV, which is what the reference's Jetson runs), so the
+// result does not depend on reduction order and matches the CPU restatement bit for bit.
+//
+// GFTT: min-eigenvalue map (Sobel 3x3 → products → 3x3 box, f64 box accumulation as cv::boxFilter),
+// masked max (order-encoded atomicMax), threshold + 3x3 non-maximum test + ordered compaction,
+// stable radix sort by value (descending, ties by higher address first), and the sequential
+// minimum-distance pick done by one wavefront with ballot-resolved conflicts.
+#include <algorithm>
+
+#include "lvi_sort.hpp"
+
+namespace lvi {
+
+namespace {
+
+constexpr int MAX_LEVELS = 8;
+constexpr int LK_WIN_MAX = 21;
+
+struct Level { uint8_t* px; int w, h; };
+struct Pyr { Level lv[MAX_LEVELS]; int top; };
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------- pyrDown
+__global__ __launch_bounds__(256) void pyrdown_kernel(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst, int dw, int dh)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= dw || y >= dh) return;
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int sy = reflect101(2 * y + j - 2, sh);
+        const uint8_t* row = src + (size_t)sy * sw;
+        const int r = row[reflect101(2 * x - 2, sw)] + 4 * row[reflect101(2 * x - 1, sw)] + 6 * row[2 * x < sw ? 2 * x : reflect101(2 * x, sw)]
+                    + 4 * row[reflect101(2 * x + 1, sw)] + row[reflect101(2 * x + 2, sw)];
+        sum += (j == 0 || j == 4) ? r : (j == 2 ? 6 * r : 4 * r);
+    }
+    dst[(size_t)y * dw + x] = (uint8_t)((sum + 128) >> 8);
+}
+
+// ------------------------------------------------------------------------------------------- LK
+struct LkArgs {
+    Pyr prev, next;
+    const float* prev_xy; float* next_xy; uint8_t* status; float* err;
+    int n, win, max_level, max_count;
+    double epsilon; float min_eig;
+};
+
+#define LVI_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+__device__ __forceinline__ int cv_floor(float v) { const int i = (int)v; return i - (i > v); }
+__device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
+
+__global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
+{
+    constexpr int TW = LK_WIN_MAX + 3;             // 24: source tile (window + 1 for bilinear + 1 on each side for Scharr)
+    constexpr int DW = LK_WIN_MAX + 1;             // 22: derivative / target tile
+    constexpr int NPX = (LK_WIN_MAX * LK_WIN_MAX + 63) / 64;   // 7 window pixels per lane
+    __shared__ uint8_t sI[TW * TW];
+    __shared__ short sD[DW * DW * 2];
+    __shared__ uint8_t sJ[DW * DW];
+    const int f = blockIdx.x, l = threadIdx.x;
+    if (f >= a.n) return;
+    const int win = a.win;
+    const float halfWin = (win - 1) * 0.5f;
+    const float px0 = a.prev_xy[2 * f], py0 = a.prev_xy[2 * f + 1];
+    float outx = 0.f, outy = 0.f, errv = 0.f;
+    bool st = true;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+
+    for (int level = a.max_level; level >= 0; level--) {
+        const Level I = a.prev.lv[level], J = a.next.lv[level];
+        float prevx = px0 * (float)(1. / (1 << level)), prevy = py0 * (float)(1. / (1 << level));
+        float nextx, nexty;
+        if (level == a.max_level) { nextx = prevx; nexty = prevy; }
+        else { nextx = outx * 2.f; nexty = outy * 2.f; }
+        outx = nextx; outy = nexty;
+        prevx -= halfWin; prevy -= halfWin;
+        const int ipx = cv_floor(prevx), ipy = cv_floor(prevy);
+        if (ipx < -win || ipx >= I.w || ipy < -win || ipy >= I.h) {
+            if (level == 0) { st = false; errv = 0.f; }
+            continue;
+        }
+        // ---- stage the source tile (REFLECT_101 border of the pyramid level) and its Scharr derivatives
+        __syncthreads();
+        for (int t = l; t < TW * TW; t += 64) {
+            const int ty = t / TW, tx = t - ty * TW;
+            sI[t] = I.px[(size_t)reflect101(ipy - 1 + ty, I.h) * I.w + reflect101(ipx - 1 + tx, I.w)];
+        }
+        __syncthreads();
+        for (int t = l; t < DW * DW; t += 64) {
+            const int dy_ = t / DW, dx_ = t - dy_ * DW;
+            const int X = ipx + dx_, Y = ipy + dy_;
+            short gx = 0, gy = 0;
+            if (X >= 0 && X < I.w && Y >= 0 && Y < I.h) {     // the derivative image is zero outside the level
+                const uint8_t* c = &sI[(dy_ + 1) * TW + (dx_ + 1)];
+                const int p00 = c[-TW - 1], p01 = c[-TW], p02 = c[-TW + 1], p10 = c[-1], p12 = c[1], p20 = c[TW - 1], p21 = c[TW], p22 = c[TW + 1];
+                gx = (short)(((p02 + p22) * 3 + p12 * 10) - ((p00 + p20) * 3 + p10 * 10));
+                gy = (short)(((p20 - p00) + (p22 - p02)) * 3 + (p21 - p01) * 10);
+            }
+            sD[2 * t] = gx; sD[2 * t + 1] = gy;
+        }
+        __syncthreads();
+        float aa = prevx - ipx, bb = prevy - ipy;
+        int iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
+        int iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
+        int iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        short Iw[NPX], Ix[NPX], Iy[NPX];
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            const int p = l + 64 * j;
+            Iw[j] = 0; Ix[j] = 0; Iy[j] = 0;
+            if (p < win * win) {
+                const int y = p / win, x = p - y * win;
+                const uint8_t* s = &sI[(y + 1) * TW + (x + 1)];
+                const int ival = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[TW] * iw10 + s[TW + 1] * iw11, W_BITS - 5);
+                const short* d = &sD[2 * (y * DW + x)];
+                const int ixval = LVI_DESCALE(d[0] * iw00 + d[2] * iw01 + d[2 * DW] * iw10 + d[2 * DW + 2] * iw11, W_BITS);
+                const int iyval = LVI_DESCALE(d[1] * iw00 + d[3] * iw01 + d[2 * DW + 1] * iw10 + d[2 * DW + 3] * iw11, W_BITS);
+                Iw[j] = (short)ival; Ix[j] = (short)ixval; Iy[j] = (short)iyval;
+                sA11 += ixval * ixval; sA12 += ixval * iyval; sA22 += iyval * iyval;
+            }
+        }
+        sA11 = wave_sum(sA11); sA12 = wave_sum(sA12); sA22 = wave_sum(sA22);
+        const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
+        if (minEig < a.min_eig || D < 1.1920929e-7f) {
+            if (level == 0) st = false;
+            continue;
+        }
+        D = 1.f / D;
+        nextx -= halfWin; nexty -= halfWin;
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < a.max_count; j++) {
+            const int inx = cv_floor(nextx), iny = cv_floor(nexty);
+            if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
+                if (level == 0) st = false;
+                break;
+            }
+            __syncthreads();
+            for (int t = l; t < DW * DW; t += 64) {
+                const int ty = t / DW, tx = t - ty * DW;
+                sJ[t] = J.px[(size_t)reflect101(iny + ty, J.h) * J.w + reflect101(inx + tx, J.w)];
+            }
+            __syncthreads();
+            aa = nextx - inx; bb = nexty - iny;
+            iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
+            iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
+            iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            long long ib1 = 0, ib2 = 0;
+#pragma unroll
+            for (int q = 0; q < NPX; q++) {
+                const int p = l + 64 * q;
+                if (p < win * win) {
+                    const int y = p / win, x = p - y * win;
+                    const uint8_t* s = &sJ[y * DW + x];
+                    const int diff = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[DW] * iw10 + s[DW + 1] * iw11, W_BITS - 5) - Iw[q];
+                    ib1 += diff * Ix[q]; ib2 += diff * Iy[q];
+                }
+            }
+            ib1 = wave_sum(ib1); ib2 = wave_sum(ib2);
+            const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+            const float dx = (float)((A12 * b2 - A22 * b1) * D);
+            const float dy = (float)((A12 * b1 - A11 * b2) * D);
+            nextx += dx; nexty += dy;
+            outx = nextx + halfWin; outy = nexty + halfWin;
+            if ((double)dx * dx + (double)dy * dy <= a.epsilon) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (st && level == 0) {
+            const float nx = outx - halfWin, ny = outy - halfWin;
+            const int inx = cv_floor(nx), iny = cv_floor(ny);
+            if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) { st = false; continue; }
+            __syncthreads();
+            for (int t = l; t < DW * DW; t += 64) {
+                const int ty = t / DW, tx = t - ty * DW;
+                sJ[t] = J.px[(size_t)reflect101(iny + ty, J.h) * J.w + reflect101(inx + tx, J.w)];
+            }
+            __syncthreads();
+            aa = nx - inx; bb = ny - iny;
+            iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
+            iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
+            iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            int esum = 0;                                  // |diff| are integers; the f32 sum of OpenCV is exact (< 2^24)
+#pragma unroll
+            for (int q = 0; q < NPX; q++) {
+                const int p = l + 64 * q;
+                if (p < win * win) {
+                    const int y = p / win, x = p - y * win;
+                    const uint8_t* s = &sJ[y * DW + x];
+                    const int diff = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[DW] * iw10 + s[DW + 1] * iw11, W_BITS - 5) - Iw[q];
+                    esum += abs(diff);
+                }
+            }
+            esum = wave_sum(esum);
+            errv = (float)esum * 1.f / (32 * win * win);
+        }
+    }
+    if (l == 0) {
+        a.next_xy[2 * f] = outx; a.next_xy[2 * f + 1] = outy;
+        a.status[f] = st ? 1 : 0; a.err[f] = errv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- GFTT
+struct GfttArgs {
+    const uint8_t* img; const uint8_t* mask; int w, h;
+    float* eig; unsigned* maxord; float* thr;
+    int* blockCnt; int* total;
+    unsigned *keysA, *valsA;
+    int *d_n, *d_nbits;
+    double quality;
+};
+
+__device__ __forceinline__ void sobel_at(const uint8_t* img, int w, int h, int x, int y, float k0, float k1, float& Dx, float& Dy)
+{
+    // evaluated at in-image (x,y); neighbours through REFLECT_101
+    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    const uint8_t *r0 = img + (size_t)ym * w, *r1 = img + (size_t)y * w, *r2 = img + (size_t)yp * w;
+    const float a0 = r0[xm], a1 = r0[x], a2 = r0[xp], b0 = r1[xm], b2 = r1[xp], c0 = r2[xm], c1 = r2[x], c2 = r2[xp];
+    // dx: row [-1 0 1] exact, column [1 2 1]*scale:  (S0 + S2)*k1 + S1*k0
+    const float S0 = a2 - a0, S1 = b2 - b0, S2 = c2 - c0;
+    const float u = (S0 + S2) * k1, v = S1 * k0;
+    Dx = u + v;
+    // dy: row [1 2 1]*scale: S[0]*k0 + (S[-1]+S[1])*k1, column [-1 0 1]
+    const float t0 = a1 * k0, t1 = (a0 + a2) * k1, rs0 = t0 + t1;
+    const float t2 = c1 * k0, t3 = (c0 + c2) * k1, rs2 = t2 + t3;
+    Dy = rs2 - rs0;
+}
+
+__global__ __launch_bounds__(256) void mineig_kernel(GfttArgs a)
+{
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    float val = 0.f; bool in = (x < a.w && y < a.h);
+    if (in) {
+        const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+        const float k1 = (float)(1.0 * scale), k0 = (float)(2.0 * scale);
+        double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int j = -1; j <= 1; j++) {
+            const int yy = reflect101(y + j, a.h);
+#pragma unroll
+            for (int i = -1; i <= 1; i++) {
+                const int xx = reflect101(x + i, a.w);
+                float dx, dy;
+                sobel_at(a.img, a.w, a.h, xx, yy, k0, k1, dx, dy);
+                const float xx2 = dx * dx, xy = dx * dy, yy2 = dy * dy;
+                s0 += xx2; s1 += xy; s2 += yy2;
+            }
+        }
+        const float A = (float)s0 * 0.5f, B = (float)s1, C = (float)s2 * 0.5f;
+        const float t = (A - C) * (A - C), u = B * B;
+        val = (A + C) - sqrtf(t + u);
+        a.eig[(size_t)y * a.w + x] = val;
+    }
+    // masked maximum (minMaxLoc with mask)
+    const bool counted = in && (!a.mask || a.mask[(size_t)y * a.w + x]);
+    unsigned o = counted ? f2ord(val) : 0u;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { const unsigned t = __shfl_xor(o, s, 64); o = t > o ? t : o; }
+    if (lane_id() == 0 && o) atomicMax(a.maxord, o);
+}
+
+__global__ void gftt_thr_kernel(GfttArgs a)
+{
+    const unsigned o = *a.maxord;
+    const double maxVal = o ? (double)ord2f(o) : 0.0;
+    *a.thr = (float)(maxVal * a.quality);
+    *a.total = 0;
+}
+
+__device__ __forceinline__ bool gftt_is_cand(const GfttArgs& a, int x, int y, float thr)
+{
+    if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) return false;
+    const float* e = a.eig + (size_t)y * a.w + x;
+    const float val = e[0];
+    if (!(val > thr) || val == 0.f) return false;
+    if (a.mask && !a.mask[(size_t)y * a.w + x]) return false;
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+        for (int i = -1; i <= 1; i++) { const float nv = e[j * a.w + i]; if (nv > thr && nv > val) return false; }
+    return true;
+}
+
+constexpr int CAND_TILE = 1024;
+__global__ __launch_bounds__(256) void gftt_count_kernel(GfttArgs a)
+{
+    const float thr = *a.thr;
+    const int base = blockIdx.x * CAND_TILE;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int p = base + threadIdx.x * 4 + j; if (p < a.w * a.h && gftt_is_cand(a, p % a.w, p / a.w, thr)) c++; }
+    __shared__ int ws[8];
+    int tot;
+    block_excl_scan<256>(c, ws, &tot);
+    if (threadIdx.x == 0) a.blockCnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void gftt_scan_kernel(GfttArgs a, int nblk)
+{
+    __shared__ int ws[8];
+    int carry = 0;
+    for (int c = 0; c < nblk; c += 256) {
+        const int i = c + threadIdx.x;
+        const int v = (i < nblk) ? a.blockCnt[i] : 0;
+        int tot;
+        const int ex = block_excl_scan<256>(v, ws, &tot);
+        if (i < nblk) a.blockCnt[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { *a.total = carry; a.d_n[0] = carry; a.d_nbits[0] = 32; }
+}
+__global__ __launch_bounds__(256) void gftt_emit_kernel(GfttArgs a)
+{
+    const float thr = *a.thr;
+    const int total = *a.total;
+    const int base = blockIdx.x * CAND_TILE;
+    bool h[4]; int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int p = base + threadIdx.x * 4 + j; h[j] = (p < a.w * a.h) && gftt_is_cand(a, p % a.w, p / a.w, thr); c += h[j]; }
+    __shared__ int ws[8];
+    int r = a.blockCnt[blockIdx.x] + block_excl_scan<256>(c, ws, nullptr);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!h[j]) continue;
+        const int p = base + threadIdx.x * 4 + j;
+        // emit in DESCENDING address order: the stable sort by value then keeps "higher address first" among ties
+        const int pos = total - 1 - r++;
+        a.keysA[pos] = ~__float_as_uint(a.eig[p]);          // eig > 0 here: ascending ~bits = descending value
+        a.valsA[pos] = (unsigned)p;
+    }
+}
+
+struct PickArgs {
+    const unsigned *valsA, *valsB; const int* d_nbits; const int* total;
+    int w, h, max_corners, cap; double min_dist;
+    float* out_xy; int* out_n; int* ncand;
+};
+
+// sequential minimum-distance selection (featureselect.cpp), one wavefront, ballot-resolved
+__global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
+{
+    constexpr int ACC_MAX = 4096;
+    __shared__ short ax[ACC_MAX], ay[ACC_MAX];
+    const unsigned* vals = rs_result_in_B(a.d_nbits[0]) ? a.valsB : a.valsA;
+    const int total = *a.total;
+    const int l = threadIdx.x;
+    if (l == 0) *a.ncand = total;
+    const bool filter = a.min_dist >= 1.0;
+    const int cell = filter ? (int)rint(a.min_dist) : 1;
+    const double md2 = a.min_dist * a.min_dist;
+    int nacc = 0;
+    const int limit = (a.max_corners > 0) ? min(a.max_corners, a.cap) : a.cap;
+    bool overflow = false;
+    for (int base = 0; base < total && nacc < limit; base += 64) {
+        const int i = base + l;
+        bool alive = i < total;
+        int x = 0, y = 0;
+        if (alive) { const int p = (int)vals[i]; y = p / a.w; x = p - y * a.w; }
+        const int xc = x / cell, yc = y / cell;
+        if (alive && filter) {
+            for (int k = 0; k < nacc; k++) {
+                const int dxc = ax[k] / cell - xc, dyc = ay[k] / cell - yc;
+                if (dxc < -1 || dxc > 1 || dyc < -1 || dyc > 1) continue;
+                const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
+                if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
+            }
+        }
+        uint64_t m = __ballot(alive);
+        while (m && nacc < limit) {
+            const int first = __ffsll((long long)m) - 1;
+            const int fx = __shfl(x, first, 64), fy = __shfl(y, first, 64);
+            if (l == first) {
+                if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; }
+                a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y;
+                alive = false;
+            }
+            nacc++;
+            if (alive && filter) {
+                const int dxc = fx / cell - xc, dyc = fy / cell - yc;
+                if (dxc >= -1 && dxc <= 1 && dyc >= -1 && dyc <= 1) {
+                    const float dx = (float)(x - fx), dy = (float)(y - fy);
+                    if ((double)(dx * dx + dy * dy) < md2) alive = false;
+                }
+            }
+            m = __ballot(alive);
+            if (nacc >= ACC_MAX && filter) { overflow = true; break; }
+        }
+        if (overflow) break;
+        __syncthreads();
+    }
+    if (l == 0) *a.out_n = overflow ? -1 : nacc;
+}
+
+int32_t tfail(int32_t code, const std::string& msg) { set_error(msg); return code; }
+
+}  // namespace
+
+}  // namespace lvi
+
+using namespace lvi;
+
+struct lvi_tracker {
+    lvi_tracker_params P;
+    int device = 0;
+    Ctx ctx; Profiler prof; Arena arena;
+    Pyr pyr[2];                 // [cur, forw]
+    int cur = 0, forw = 1;
+    int w = 0, h = 0;
+    bool have_forw = false, have_cur = false, have_lk = false, have_gftt = false, have_mask = false;
+    uint8_t* d_stage = nullptr;
+    float *d_cur_xy = nullptr, *d_forw_xy = nullptr, *d_err = nullptr; uint8_t* d_status = nullptr; int n_pts = 0;
+    uint8_t* d_mask = nullptr; float* d_eig = nullptr; unsigned* d_maxord = nullptr; float* d_thr = nullptr;
+    int *d_blockCnt = nullptr, *d_total = nullptr, *d_n = nullptr, *d_nbits = nullptr, *d_out_n = nullptr, *d_ncand = nullptr;
+    float* d_gftt_xy = nullptr;
+    SortPlan sort;
+    int gftt_n = 0, gftt_ncand = 0;
+};
+
+namespace {
+
+template <class F>
+int32_t tguard(lvi_tracker* t, F&& f)
+{
+    try {
+        if (t) LVI_HIP(hipSetDevice(t->device));
+        return f();
+    } catch (const HipError& e) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", e.what, hipGetErrorString(e.e), e.file, e.line);
+        return tfail(LVI_ERR_HIP, buf);
+    }
+}
+
+template <class AR>
+void tracker_layout(AR& ar, lvi_tracker& t)
+{
+    const int W = t.P.max_width, H = t.P.max_height;
+    for (int s = 0; s < 2; s++) {
+        int w = W, h = H;
+        for (int l = 0; l <= t.P.lk_max_level; l++) {
+            t.pyr[s].lv[l].px = ar.template alloc<uint8_t>((size_t)w * h);
+            w = (w + 1) / 2; h = (h + 1) / 2;
+        }
+    }
+    const int F = std::max(t.P.max_features, 64);
+    t.d_cur_xy = ar.template alloc<float>(2 * (size_t)F); t.d_forw_xy = ar.template alloc<float>(2 * (size_t)F);
+    t.d_err = ar.template alloc<float>(F); t.d_status = ar.template alloc<uint8_t>(F);
+    t.d_mask = ar.template alloc<uint8_t>((size_t)W * H); t.d_eig = ar.template alloc<float>((size_t)W * H);
+    t.d_maxord = ar.template alloc<unsigned>(1); t.d_thr = ar.template alloc<float>(1);
+    t.d_blockCnt = ar.template alloc<int>(div_up(W * H, CAND_TILE) + 1);
+    t.d_total = ar.template alloc<int>(1); t.d_n = ar.template alloc<int>(1); t.d_nbits = ar.template alloc<int>(1);
+    t.d_out_n = ar.template alloc<int>(1); t.d_ncand = ar.template alloc<int>(1);
+    t.d_gftt_xy = ar.template alloc<float>(2 * (size_t)F);
+    t.sort.allocate(ar, 1, W * H);
+}
+
+void build_pyramid(lvi_tracker& t, int slot)
+{
+    Pyr& p = t.pyr[slot];
+    int w = t.w, h = t.h;
+    p.lv[0].w = w; p.lv[0].h = h;
+    p.top = t.P.lk_max_level;
+    for (int level = 0; level <= t.P.lk_max_level; level++) {
+        if (level != 0) {
+            const int dw = (p.lv[level - 1].w + 1) / 2, dh = (p.lv[level - 1].h + 1) / 2;
+            p.lv[level].w = dw; p.lv[level].h = dh;
+            LVI_LAUNCH(t.ctx, "pyrdown", (double)p.lv[level - 1].w * p.lv[level - 1].h + (double)dw * dh,
+                       hipLaunchKernelGGL(pyrdown_kernel, dim3(div_up(dw, 32), div_up(dh, 8)), dim3(256), 0, t.ctx.stream,
+                                          p.lv[level - 1].px, p.lv[level - 1].w, p.lv[level - 1].h, p.lv[level].px, dw, dh));
+        }
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= t.P.lk_win || h <= t.P.lk_win) { p.top = level; break; }      // buildOpticalFlowPyramid's early return
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
 void lvi_tracker_params_default(lvi_tracker_params* p)
 {
     memset(p, 0, sizeof(*p));
@@ -9,20 +511,267 @@ void lvi_tracker_params_default(lvi_tracker_params* p)
     p->lk_win = 21; p->lk_max_level = 3; p->lk_max_iters = 30; p->lk_eps = 0.01; p->lk_min_eig_threshold = 1e-4f;
     p->gftt_quality = 0.01; p->max_features = 1024;
 }
-int32_t lvi_tracker_create(const lvi_tracker_params*, int32_t, lvi_tracker**) { return nyi(); }
-void lvi_tracker_destroy(lvi_tracker*) {}
-int32_t lvi_tracker_sync(lvi_tracker*) { return nyi(); }
-int32_t lvi_lk_track(lvi_tracker*, const uint8_t*, const uint8_t*, int32_t, int32_t, int32_t, const float*, int32_t, float*, uint8_t*, float*) { return nyi(); }
-int32_t lvi_good_features(lvi_tracker*, const uint8_t*, const uint8_t*, int32_t, int32_t, int32_t, int32_t, double, double, float*, int32_t, int32_t*) { return nyi(); }
-int32_t lvi_tracker_push_image(lvi_tracker*, const uint8_t*, int32_t, int32_t, int32_t) { return nyi(); }
-int32_t lvi_tracker_set_points(lvi_tracker*, const float*, int32_t) { return nyi(); }
-int32_t lvi_tracker_run_lk(lvi_tracker*) { return nyi(); }
-int32_t lvi_tracker_get_lk(lvi_tracker*, float*, uint8_t*, float*, int32_t, int32_t*) { return nyi(); }
-int32_t lvi_tracker_set_mask(lvi_tracker*, const uint8_t*, int32_t, int32_t, int32_t) { return nyi(); }
-int32_t lvi_tracker_run_gftt(lvi_tracker*, int32_t) { return nyi(); }
-int32_t lvi_tracker_get_gftt(lvi_tracker*, float*, int32_t, int32_t*) { return nyi(); }
-int32_t lvi_tracker_debug_get(lvi_tracker*, int32_t, void*, int64_t, int64_t*) { return nyi(); }
-int32_t lvi_tracker_prof_enable(lvi_tracker*, int32_t) { return nyi(); }
-int32_t lvi_tracker_prof_reset(lvi_tracker*) { return nyi(); }
-int32_t lvi_tracker_prof_read(lvi_tracker*, lvi_kernel_stat*, int32_t, int32_t*) { return nyi(); }
+
+int32_t lvi_tracker_create(const lvi_tracker_params* p, int32_t device, lvi_tracker** out)
+{
+    if (!p || !out) return tfail(LVI_ERR_INVALID_ARG, "null argument");
+    if (p->lk_win < 3 || (p->lk_win & 1) == 0 || p->lk_win > LK_WIN_MAX || p->lk_max_level < 0 || p->lk_max_level >= MAX_LEVELS)
+        return tfail(LVI_ERR_INVALID_ARG, "bad LK parameters (odd window <= 21, maxLevel 0..7)");
+    if (p->max_width <= 0 || p->max_height <= 0 || p->max_features <= 0 || p->max_features > 4096) return tfail(LVI_ERR_INVALID_ARG, "bad capacities");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return tfail(LVI_ERR_NO_DEVICE, "no HIP device: the HIP path has no CPU fallback");
+    if (device < 0 || device >= ndev) return tfail(LVI_ERR_NO_DEVICE, "device index out of range");
+    lvi_tracker* t = new lvi_tracker();
+    t->P = *p; t->device = device;
+    int32_t st = tguard(t, [&]() -> int32_t {
+        LVI_HIP(hipStreamCreateWithFlags(&t->ctx.stream, hipStreamNonBlocking));
+        t->ctx.prof = &t->prof;
+        ArenaSizer sz; tracker_layout(sz, *t);
+        t->arena.init(sz.used + (1 << 16));
+        tracker_layout(t->arena, *t);
+        LVI_HIP(hipMemsetAsync(t->arena.base, 0, t->arena.size, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        return LVI_OK;
+    });
+    if (st != LVI_OK) { lvi_tracker_destroy(t); return st; }
+    *out = t;
+    return LVI_OK;
 }
+
+void lvi_tracker_destroy(lvi_tracker* t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->ctx.stream) (void)hipStreamSynchronize(t->ctx.stream);
+    t->prof.collect();
+    t->arena.release();
+    if (t->ctx.stream) (void)hipStreamDestroy(t->ctx.stream);
+    delete t;
+}
+
+int32_t lvi_tracker_sync(lvi_tracker* t)
+{
+    if (!t) return tfail(LVI_ERR_INVALID_ARG, "null handle");
+    return tguard(t, [&]() -> int32_t { LVI_HIP(hipStreamSynchronize(t->ctx.stream)); return LVI_OK; });
+}
+
+int32_t lvi_tracker_push_image(lvi_tracker* t, const uint8_t* img, int32_t w, int32_t h, int32_t stride)
+{
+    if (!t || !img || w <= 0 || h <= 0 || stride < w) return tfail(LVI_ERR_INVALID_ARG, "bad image");
+    if (w > t->P.max_width || h > t->P.max_height) return tfail(LVI_ERR_CAPACITY, "image exceeds capacity");
+    return tguard(t, [&]() -> int32_t {
+        if (t->have_forw && (w != t->w || h != t->h)) { t->have_forw = t->have_cur = false; }
+        if (t->have_forw) { std::swap(t->cur, t->forw); t->have_cur = true; }     // cur_img = forw_img (:203)
+        t->w = w; t->h = h;
+        LVI_HIP(hipMemcpy2DAsync(t->pyr[t->forw].lv[0].px, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
+        build_pyramid(*t, t->forw);
+        if (!t->have_forw) {                                                       // prev = cur = forw = img (:94-97)
+            LVI_HIP(hipMemcpyAsync(t->pyr[t->cur].lv[0].px, t->pyr[t->forw].lv[0].px, (size_t)w * h, hipMemcpyDeviceToDevice, t->ctx.stream));
+            build_pyramid(*t, t->cur);
+            t->have_cur = true;
+        }
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));                               // caller may reuse its buffer
+        t->have_forw = true; t->have_lk = false; t->have_gftt = false;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_set_points(lvi_tracker* t, const float* cur_xy, int32_t n)
+{
+    if (!t || n < 0 || (n > 0 && !cur_xy)) return tfail(LVI_ERR_INVALID_ARG, "bad points");
+    if (n > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many points");
+    return tguard(t, [&]() -> int32_t {
+        if (n) LVI_HIP(hipMemcpyAsync(t->d_cur_xy, cur_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        t->n_pts = n; t->have_lk = false;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_run_lk(lvi_tracker* t)
+{
+    if (!t || !t->have_forw || !t->have_cur) return tfail(LVI_ERR_STATE, "no image pair");
+    return tguard(t, [&]() -> int32_t {
+        LkArgs a{};
+        a.prev = t->pyr[t->cur]; a.next = t->pyr[t->forw];
+        a.prev_xy = t->d_cur_xy; a.next_xy = t->d_forw_xy; a.status = t->d_status; a.err = t->d_err;
+        a.n = t->n_pts; a.win = t->P.lk_win; a.max_level = std::min(a.prev.top, a.next.top);
+        a.max_count = std::min(std::max(t->P.lk_max_iters, 0), 100);
+        double eps = std::min(std::max(t->P.lk_eps, 0.), 10.);
+        a.epsilon = eps * eps; a.min_eig = t->P.lk_min_eig_threshold;
+        if (a.n > 0) {
+            const double bytes = (double)a.n * (a.max_level + 1) * (24.0 * 24 + 22.0 * 22 * 4);
+            LVI_LAUNCH(t->ctx, "lk_track", bytes, hipLaunchKernelGGL(lk_kernel, dim3(a.n), dim3(64), 0, t->ctx.stream, a));
+        }
+        t->have_lk = true;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_get_lk(lvi_tracker* t, float* forw_xy, uint8_t* status, float* err, int32_t capacity, int32_t* n)
+{
+    if (!t || !n) return tfail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!t->have_lk) return tfail(LVI_ERR_STATE, "LK not run");
+    *n = t->n_pts;
+    if (capacity < *n) return tfail(LVI_ERR_CAPACITY, "capacity too small");
+    return tguard(t, [&]() -> int32_t {
+        const int m = *n;
+        if (m && forw_xy) LVI_HIP(hipMemcpyAsync(forw_xy, t->d_forw_xy, sizeof(float) * 2 * m, hipMemcpyDeviceToHost, t->ctx.stream));
+        if (m && status) LVI_HIP(hipMemcpyAsync(status, t->d_status, (size_t)m, hipMemcpyDeviceToHost, t->ctx.stream));
+        if (m && err) LVI_HIP(hipMemcpyAsync(err, t->d_err, sizeof(float) * m, hipMemcpyDeviceToHost, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_set_mask(lvi_tracker* t, const uint8_t* mask, int32_t w, int32_t h, int32_t stride)
+{
+    if (!t) return tfail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!mask) { t->have_mask = false; return LVI_OK; }
+    if (!t->have_forw || w != t->w || h != t->h || stride < w) return tfail(LVI_ERR_INVALID_ARG, "mask size mismatch");
+    return tguard(t, [&]() -> int32_t {
+        LVI_HIP(hipMemcpy2DAsync(t->d_mask, (size_t)w, mask, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        t->have_mask = true;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_run_gftt(lvi_tracker* t, int32_t max_corners)
+{
+    if (!t || !t->have_forw) return tfail(LVI_ERR_STATE, "no image");
+    return tguard(t, [&]() -> int32_t {
+        const int w = t->w, h = t->h, npx = w * h;
+        GfttArgs a{};
+        a.img = t->pyr[t->forw].lv[0].px; a.mask = t->have_mask ? t->d_mask : nullptr; a.w = w; a.h = h;
+        a.eig = t->d_eig; a.maxord = t->d_maxord; a.thr = t->d_thr; a.blockCnt = t->d_blockCnt; a.total = t->d_total;
+        a.keysA = t->sort.keysA; a.valsA = t->sort.valsA; a.d_n = t->d_n; a.d_nbits = t->d_nbits; a.quality = t->P.gftt_quality;
+        const int nblk = div_up(npx, CAND_TILE);
+        LVI_HIP(hipMemsetAsync(t->d_maxord, 0, sizeof(unsigned), t->ctx.stream));
+        LVI_LAUNCH(t->ctx, "gftt_mineig", 2.0 * npx + 4.0 * npx, hipLaunchKernelGGL(mineig_kernel, dim3(div_up(w, 32), div_up(h, 8)), dim3(256), 0, t->ctx.stream, a));
+        LVI_LAUNCH(t->ctx, "gftt_thr", 0, hipLaunchKernelGGL(gftt_thr_kernel, dim3(1), dim3(1), 0, t->ctx.stream, a));
+        LVI_LAUNCH(t->ctx, "gftt_count", 5.0 * npx, hipLaunchKernelGGL(gftt_count_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
+        LVI_LAUNCH(t->ctx, "gftt_scan", 0, hipLaunchKernelGGL(gftt_scan_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, nblk));
+        LVI_LAUNCH(t->ctx, "gftt_emit", 5.0 * npx, hipLaunchKernelGGL(gftt_emit_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
+        radix_sort_pairs(t->ctx, t->sort, t->d_n, t->d_nbits, 4, "gftt", 0.02 * npx);
+        PickArgs p{};
+        p.valsA = t->sort.valsA; p.valsB = t->sort.valsB; p.d_nbits = t->d_nbits; p.total = t->d_total;
+        p.w = w; p.h = h; p.max_corners = max_corners; p.cap = t->P.max_features; p.min_dist = t->P.min_dist;
+        p.out_xy = t->d_gftt_xy; p.out_n = t->d_out_n; p.ncand = t->d_ncand;
+        LVI_LAUNCH(t->ctx, "gftt_pick", 0, hipLaunchKernelGGL(gftt_pick_kernel, dim3(1), dim3(64), 0, t->ctx.stream, p));
+        int res[2] = {0, 0};
+        LVI_HIP(hipMemcpyAsync(&res[0], t->d_out_n, sizeof(int), hipMemcpyDeviceToHost, t->ctx.stream));
+        LVI_HIP(hipMemcpyAsync(&res[1], t->d_ncand, sizeof(int), hipMemcpyDeviceToHost, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        if (res[0] < 0) return tfail(LVI_ERR_CAPACITY, "more corners than the pick kernel's accepted-list capacity");
+        if (max_corners <= 0 && res[0] >= t->P.max_features) return tfail(LVI_ERR_CAPACITY, "more corners than max_features");
+        t->gftt_n = res[0]; t->gftt_ncand = res[1]; t->have_gftt = true;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_get_gftt(lvi_tracker* t, float* xy, int32_t capacity, int32_t* n)
+{
+    if (!t || !n) return tfail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!t->have_gftt) return tfail(LVI_ERR_STATE, "GFTT not run");
+    *n = t->gftt_n;
+    if (capacity < *n) return tfail(LVI_ERR_CAPACITY, "capacity too small");
+    return tguard(t, [&]() -> int32_t {
+        if (*n && xy) LVI_HIP(hipMemcpyAsync(xy, t->d_gftt_xy, sizeof(float) * 2 * *n, hipMemcpyDeviceToHost, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_lk_track(lvi_tracker* t, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h, int32_t stride,
+                     const float* prev_xy, int32_t n, float* next_xy, uint8_t* status, float* err)
+{
+    if (!t || !prev || !next || n < 0) return tfail(LVI_ERR_INVALID_ARG, "bad arguments");
+    t->have_forw = false; t->have_cur = false;
+    int32_t st = lvi_tracker_push_image(t, prev, w, h, stride); if (st) return st;
+    st = lvi_tracker_push_image(t, next, w, h, stride); if (st) return st;
+    st = lvi_tracker_set_points(t, prev_xy, n); if (st) return st;
+    st = lvi_tracker_run_lk(t); if (st) return st;
+    int32_t m = 0;
+    return lvi_tracker_get_lk(t, next_xy, status, err, n, &m);
+}
+
+int32_t lvi_good_features(lvi_tracker* t, const uint8_t* img, const uint8_t* mask, int32_t w, int32_t h, int32_t stride,
+                          int32_t max_corners, double quality, double min_dist, float* xy, int32_t xy_capacity, int32_t* n_out)
+{
+    if (!t || !img || !n_out) return tfail(LVI_ERR_INVALID_ARG, "bad arguments");
+    t->have_forw = false; t->have_cur = false;
+    int32_t st = lvi_tracker_push_image(t, img, w, h, stride); if (st) return st;
+    st = lvi_tracker_set_mask(t, mask, w, h, stride); if (st) return st;
+    const double q0 = t->P.gftt_quality, d0 = t->P.min_dist;
+    t->P.gftt_quality = quality; t->P.min_dist = min_dist;
+    st = lvi_tracker_run_gftt(t, max_corners);
+    t->P.gftt_quality = q0; t->P.min_dist = d0;
+    if (st) return st;
+    return lvi_tracker_get_gftt(t, xy, xy_capacity, n_out);
+}
+
+int32_t lvi_tracker_debug_get(lvi_tracker* t, int32_t what, void* dst, int64_t cap, int64_t* n_bytes)
+{
+    if (!t) return tfail(LVI_ERR_INVALID_ARG, "null handle");
+    return tguard(t, [&]() -> int32_t {
+        const void* src = nullptr; int64_t bytes = 0; int32_t host_val = 0; bool host = false;
+        switch (what) {
+            case LVI_TDBG_PYRAMID_L1: case LVI_TDBG_PYRAMID_L2: case LVI_TDBG_PYRAMID_L3: {
+                const int l = what - LVI_TDBG_PYRAMID_L1 + 1;
+                if (!t->have_forw || l > t->pyr[t->forw].top) return tfail(LVI_ERR_STATE, "level not built");
+                src = t->pyr[t->forw].lv[l].px; bytes = (int64_t)t->pyr[t->forw].lv[l].w * t->pyr[t->forw].lv[l].h;
+                break;
+            }
+            case LVI_TDBG_MINEIG:
+                if (!t->have_gftt) return tfail(LVI_ERR_STATE, "GFTT not run");
+                src = t->d_eig; bytes = (int64_t)t->w * t->h * 4;
+                break;
+            case LVI_TDBG_GFTT_NCAND:
+                if (!t->have_gftt) return tfail(LVI_ERR_STATE, "GFTT not run");
+                host = true; host_val = t->gftt_ncand; bytes = 4;
+                break;
+            default: return tfail(LVI_ERR_INVALID_ARG, "unknown debug item");
+        }
+        if (n_bytes) *n_bytes = bytes;
+        if (!dst) return LVI_OK;
+        if (cap < bytes) return tfail(LVI_ERR_CAPACITY, "debug buffer too small");
+        if (host) { memcpy(dst, &host_val, 4); return LVI_OK; }
+        LVI_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_prof_enable(lvi_tracker* t, int32_t on)
+{
+    if (!t) return tfail(LVI_ERR_INVALID_ARG, "null handle");
+    return tguard(t, [&]() -> int32_t { LVI_HIP(hipStreamSynchronize(t->ctx.stream)); t->prof.collect(); t->prof.on = on != 0; return LVI_OK; });
+}
+int32_t lvi_tracker_prof_reset(lvi_tracker* t)
+{
+    if (!t) return tfail(LVI_ERR_INVALID_ARG, "null handle");
+    return tguard(t, [&]() -> int32_t { LVI_HIP(hipStreamSynchronize(t->ctx.stream)); t->prof.reset(); return LVI_OK; });
+}
+int32_t lvi_tracker_prof_read(lvi_tracker* t, lvi_kernel_stat* stats, int32_t capacity, int32_t* n)
+{
+    if (!t || !n) return tfail(LVI_ERR_INVALID_ARG, "null argument");
+    return tguard(t, [&]() -> int32_t {
+        Profiler& p = t->prof;
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream)); p.collect();
+        int k = 0;
+        for (size_t i = 0; i < p.names.size(); i++) {
+            if (!p.launches[i]) continue;
+            if (k < capacity && stats) {
+                memset(&stats[k], 0, sizeof(stats[k]));
+                strncpy(stats[k].name, p.names[i].c_str(), sizeof(stats[k].name) - 1);
+                stats[k].launches = p.launches[i]; stats[k].total_ms = p.total_ms[i]; stats[k].bytes_alg = p.bytes[i];
+            }
+            k++;
+        }
+        *n = std::min(k, capacity);
+        return LVI_OK;
+    });
+}
+
+}  // extern "C"

@@ -129,6 +129,13 @@ class LidarHotpath:
         pts = np.ascontiguousarray(livox_pts, dtype=A.LIVOX_DTYPE)
         self.lib.check(self.lib.dll.lvi_scan_upload(self._h, A._ptr(pts), len(pts)), "lvi_scan_upload")
 
+    def scan_upload_device(self, d_ptr, n_raw):
+        self.lib.check(self.lib.dll.lvi_scan_upload_device(self._h, C.c_void_p(int(d_ptr)), int(n_raw)), "lvi_scan_upload_device")
+
+    def map_upload_device(self, d_corner, nc, d_surf, ns):
+        self.lib.check(self.lib.dll.lvi_map_upload_device(self._h, C.c_void_p(int(d_corner)), int(nc), C.c_void_p(int(d_surf)), int(ns)),
+                       "lvi_map_upload_device")
+
     def scan_organize(self):
         self.lib.check(self.lib.dll.lvi_scan_organize(self._h), "lvi_scan_organize")
 

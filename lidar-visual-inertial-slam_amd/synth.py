@@ -71,13 +71,38 @@ def raycast(origin, dirs_world, boxes=None):
     return t
 
 
-def make_scan(n_raw, pose, seed, noise=0.02):
+def raycast_torch(origin, dirs_world, device, boxes=None):
+    """same ray casting on a torch device (bench set-up only: 250 keyframe scans in seconds)"""
+    import torch
+    if boxes is None:
+        boxes = scene_boxes()
+    o = torch.as_tensor(np.asarray(origin, np.float64), device=device)
+    d = torch.as_tensor(dirs_world, device=device)
+    d = torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+    inv = 1.0 / d
+    room = torch.as_tensor(ROOM, device=device)
+    t = torch.where(d > 0, (room[:, 1] - o) * inv, (room[:, 0] - o) * inv).min(dim=1).values
+    for b in boxes:
+        bt = torch.as_tensor(b, device=device)
+        lo = (bt[0::2] - o) * inv
+        hi = (bt[1::2] - o) * inv
+        tmin = torch.minimum(lo, hi).max(dim=1).values
+        tmax = torch.maximum(lo, hi).min(dim=1).values
+        hit = (tmax >= tmin) & (tmin > 0) & (tmin < t)
+        t = torch.where(hit, tmin, t)
+    return t.cpu().numpy()
+
+
+def make_scan(n_raw, pose, seed, noise=0.02, torch_device=None):
     """one Livox CustomMsg worth of points (LIVOX_DTYPE, n_raw entries) seen from `pose`
     = (roll, pitch, yaw, x, y, z) of the sensor in the map frame"""
     rng = np.random.default_rng(seed)
     dirs, line = scan_directions(n_raw)
     R = rot_zyx(pose[0], pose[1], pose[2])
-    t = raycast(np.array(pose[3:6], np.float64), dirs @ R.T)
+    if torch_device is not None:
+        t = raycast_torch(np.array(pose[3:6], np.float64), dirs @ R.T, torch_device)
+    else:
+        t = raycast(np.array(pose[3:6], np.float64), dirs @ R.T)
     r = t + rng.normal(0.0, noise, n_raw)
     p = dirs * r[:, None]
     out = np.zeros(n_raw, A.LIVOX_DTYPE)
@@ -101,7 +126,7 @@ def transform_points(pts, pose):
     return out.view(A.PT_DTYPE).reshape(-1)
 
 
-def make_map(extractor, n_keyframes, n_raw, seed=4711, pose_sigma=(0.01, np.deg2rad(0.1))):
+def make_map(extractor, n_keyframes, n_raw, seed=4711, pose_sigma=(0.01, np.deg2rad(0.1)), torch_device=None, target_surf=None):
     """frozen local map: laserCloud{Corner,Surf}FromMap before downsampling.
 
     `extractor` is any LidarHotpath (its organize+extract stages turn each synthetic
@@ -109,10 +134,13 @@ def make_map(extractor, n_keyframes, n_raw, seed=4711, pose_sigma=(0.01, np.deg2
     clouds are moved to the map frame with the ground-truth pose plus a small error."""
     rng = np.random.default_rng(seed)
     corners, surfs = [], []
+    n_surf = 0
     for k in range(n_keyframes):
+        if target_surf is not None and n_surf >= target_surf:
+            break
         alpha = 2 * np.pi * k / n_keyframes
         pose = loop_pose(alpha, roll=rng.normal(0, 0.01), pitch=rng.normal(0, 0.01))
-        scan = make_scan(n_raw, pose, seed * 1000 + k)
+        scan = make_scan(n_raw, pose, seed * 1000 + k, torch_device=torch_device)
         extractor.scan_upload(scan)
         extractor.scan_organize()
         extractor.scan_extract()
@@ -122,7 +150,11 @@ def make_map(extractor, n_keyframes, n_raw, seed=4711, pose_sigma=(0.01, np.deg2
         noisy[3:] += rng.normal(0, pose_sigma[0], 3)
         corners.append(transform_points(c, noisy))
         surfs.append(transform_points(s, noisy))
-    return np.concatenate(corners), np.concatenate(surfs)
+        n_surf += len(s)
+    mc, ms = np.concatenate(corners), np.concatenate(surfs)
+    if target_surf is not None:
+        ms = ms[:target_surf]
+    return mc, ms
 
 
 def perturbed_guess(pose, scan_id, rot_deg=1.5, trans=0.15):

@@ -891,6 +891,8 @@ int32_t lvi_debug_residuals(lvi_lidar* h, int32_t which, const float pose[6], lv
 
 // hip-only entry points: present so that the symbol set is identical, but unsupported here
 int32_t lvi_scan_match_async(lvi_lidar*, const float*, void*) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
+int32_t lvi_scan_upload_device(lvi_lidar*, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
+int32_t lvi_map_upload_device(lvi_lidar*, const void*, int32_t, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_prof_enable(lvi_lidar*, int32_t) { return LVI_OK; }
 int32_t lvi_prof_reset(lvi_lidar*) { return LVI_OK; }
 int32_t lvi_prof_read(lvi_lidar*, lvi_kernel_stat*, int32_t, int32_t* n) { if (n) *n = 0; return LVI_OK; }
