@@ -247,12 +247,11 @@ def bench_tracker(pkg, hip, device):
     t.push_image(frames[0])
     n_iter, t_total = 40, 0.0
     for i in range(n_iter + 5):
-        f = frames[1 + i % 4]
+        f = frames[(i + 1) % 5]                      # the previous push is "cur", this one becomes "forw"
         t0 = time.perf_counter()
         t.push_image(f); t.set_points(pts); t.run_lk(); t.sync()
         if i >= 5:
             t_total += time.perf_counter() - t0
-        t.push_image(frames[0])
     xy, st, _ = t.get_lk()
     return dict(metric="lk_frames_per_sec_1280x720_150pts", value=round(n_iter / t_total, 1), unit="frames/s",
                 tracked=int(st.sum()), features=int(len(pts)), note="includes the H2D of each new 0.92 MB frame")

@@ -129,30 +129,53 @@ __device__ __forceinline__ void knn_insert(Knn5& r, float dist, int idx)
     }
 }
 
-__device__ __forceinline__ void knn5_search(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
-                                            float qx, float qy, float qz, Knn5& r)
+// G consecutive lanes share one query: every lane scans a strided share of the candidate rows
+// (adjacent lanes read adjacent 16-B points → coalesced), keeps a private top-5, then the G lists are
+// merged by 5 rounds of a group-wide (distance, index) minimum.  All G lanes end with the same result.
+constexpr int KNN_G = 8;
+
+__device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
+                                                  float qx, float qy, float qz, int sub, Knn5& out)
 {
+    Knn5 r;
 #pragma unroll
     for (int k = 0; k < 5; k++) { r.d[k] = INFINITY; r.i[k] = 0x7fffffff; }
-    if (!m.ok || m.n <= 0) return;
-    int c[3];
-    cell_of(m, qx, qy, qz, c);
-    const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, m.dim[0] - 1);
-    if (x0 > x1) return;
-    for (int dz = -1; dz <= 1; dz++) {
-        const int z = c[2] + dz;
-        if (z < 0 || z >= m.dim[2]) continue;
-        for (int dy = -1; dy <= 1; dy++) {
-            const int y = c[1] + dy;
-            if (y < 0 || y >= m.dim[1]) continue;
-            const int row = (z * m.dim[1] + y) * m.dim[0];
-            const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
-            for (int j = b; j < e; j++) {
-                const lvi_pt p = sorted[j];
-                const float ex = sub_rn(qx, p.x), ey = sub_rn(qy, p.y), ez = sub_rn(qz, p.z);
-                const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
-                knn_insert(r, dist, __float_as_int(p.intensity));
+    if (m.ok && m.n > 0) {
+        int c[3];
+        cell_of(m, qx, qy, qz, c);
+        const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, m.dim[0] - 1);
+        if (x0 <= x1) {
+            for (int dz = -1; dz <= 1; dz++) {
+                const int z = c[2] + dz;
+                if (z < 0 || z >= m.dim[2]) continue;
+                for (int dy = -1; dy <= 1; dy++) {
+                    const int y = c[1] + dy;
+                    if (y < 0 || y >= m.dim[1]) continue;
+                    const int row = (z * m.dim[1] + y) * m.dim[0];
+                    const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                    for (int j = b + sub; j < e; j += KNN_G) {
+                        const lvi_pt p = sorted[j];
+                        const float ex = sub_rn(qx, p.x), ey = sub_rn(qy, p.y), ez = sub_rn(qz, p.z);
+                        const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+                        knn_insert(r, dist, __float_as_int(p.intensity));
+                    }
+                }
             }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float hd = r.d[0]; int hi = r.i[0];
+#pragma unroll
+        for (int o = KNN_G / 2; o > 0; o >>= 1) {
+            const float od = __shfl_xor(hd, o, 64); const int oi = __shfl_xor(hi, o, 64);
+            if (od < hd || (od == hd && oi < hi)) { hd = od; hi = oi; }
+        }
+        out.d[k] = hd; out.i[k] = hi;
+        if (r.d[0] == hd && r.i[0] == hi) {           // the owner of the winner pops it (indices are unique per lane)
+#pragma unroll
+            for (int q = 0; q < 4; q++) { r.d[q] = r.d[q + 1]; r.i[q] = r.i[q + 1]; }
+            r.d[4] = INFINITY; r.i[4] = 0x7fffffff;
         }
     }
 }
@@ -160,10 +183,12 @@ __device__ __forceinline__ void knn5_search(const GridIndex::Meta& m, const int*
 __global__ __launch_bounds__(256) void knn_debug_kernel(const GridIndex::Meta* meta, const int* cell_start, const lvi_pt* sorted,
                                                         const lvi_pt* q, int nq, int* idx, float* sqd)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    // same group search the residual kernels use
+    const int t = blockIdx.x * (256 / KNN_G) + threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
     if (t >= nq) return;
     Knn5 r;
-    knn5_search(*meta, cell_start, sorted, q[t].x, q[t].y, q[t].z, r);
+    knn5_search_group(*meta, cell_start, sorted, q[t].x, q[t].y, q[t].z, sub, r);
+    if (sub != 0) return;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const bool ok = r.d[k] < 1.0f;
@@ -269,11 +294,8 @@ __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)    
     return o;
 }
 
-__device__ bool corner_residual(const IcpArgs& a, const float A[12], const lvi_pt& pointOri, lvi_pt& coeff)
+__device__ bool corner_residual(const IcpArgs& a, const lvi_pt& pointSel, const Knn5& r, lvi_pt& coeff)
 {
-    const lvi_pt pointSel = to_map(A, pointOri);
-    Knn5 r;
-    knn5_search(*a.meta[0], a.cell_start[0], a.sorted[0], pointSel.x, pointSel.y, pointSel.z, r);
     if (!(r.d[4] < 1.0f)) return false;                                            // :1025
     const lvi_pt* map = a.mapds[0];
     float cx = 0, cy = 0, cz = 0;
@@ -308,11 +330,8 @@ __device__ bool corner_residual(const IcpArgs& a, const float A[12], const lvi_p
     return s > 0.1;
 }
 
-__device__ bool surf_residual(const IcpArgs& a, const float A[12], const lvi_pt& pointOri, lvi_pt& coeff)
+__device__ bool surf_residual(const IcpArgs& a, const lvi_pt& pointOri, const lvi_pt& pointSel, const Knn5& r, lvi_pt& coeff)
 {
-    const lvi_pt pointSel = to_map(A, pointOri);
-    Knn5 r;
-    knn5_search(*a.meta[1], a.cell_start[1], a.sorted[1], pointSel.x, pointSel.y, pointSel.z, r);
     if (!(r.d[4] < 1.0f)) return false;                                            // :1121
     const lvi_pt* map = a.mapds[1];
     float M[5][3], b[5], X[3];
@@ -350,48 +369,60 @@ __device__ __forceinline__ void lm_row(const float tr[6], const lvi_pt& ori, con
     rowB = -cf.intensity;
 }
 
+constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // queries per workgroup
+
 __global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
 {
     if (a.st->done) return;
     const int nC = a.nq[0], nS = a.nq[1];
-    const int t = blockIdx.x * ICP_BLOCK + threadIdx.x;
-    if (blockIdx.x * ICP_BLOCK >= nC + nS) return;
+    if (blockIdx.x * ICP_QPB >= nC + nS) return;
     __shared__ float sA[12], sT[6];
+    __shared__ double srow[ICP_QPB][28];
     if (threadIdx.x < 12) sA[threadIdx.x] = a.st->pose.A[threadIdx.x];
     if (threadIdx.x < 6) sT[threadIdx.x] = a.st->pose.trig[threadIdx.x];
     __syncthreads();
-    double acc[28];
-#pragma unroll
-    for (int k = 0; k < 28; k++) acc[k] = 0.0;
-    if (t < nC + nS) {
-        const bool isC = t < nC;
-        const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
-        lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
-        const bool ok = isC ? corner_residual(a, sA, ori, cf) : surf_residual(a, sA, ori, cf);
+    const int ql = threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
+    const int t = blockIdx.x * ICP_QPB + ql;
+    const bool active = t < nC + nS;
+    const bool isC = t < nC;
+    lvi_pt ori = {0.f, 0.f, 0.f, 0.f};
+    if (active) ori = isC ? a.q[0][t] : a.q[1][t - nC];
+    const lvi_pt sel = to_map(sA, ori);
+    const int w = (active && !isC) ? 1 : 0;
+    Knn5 r;
+    // inactive groups search nothing (query far outside any grid is still fine, but skip the work)
+    if (active) knn5_search_group(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r);
+    bool ok = false;
+    lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
+    if (active && sub == 0) {
+        ok = isC ? corner_residual(a, sel, r, cf) : surf_residual(a, ori, sel, r, cf);
         a.flag[t] = ok ? 1 : 0;
         a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+    }
+    if (sub == 0) {
+        double* row = srow[ql];
         if (ok) {
             float rA[6], rB;
             lm_row(sT, ori, cf, rA, rB);
             int k = 0;
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+            for (int rr = 0; rr < 6; rr++)
 #pragma unroll
-                for (int c = r; c < 6; c++) acc[k++] = (double)rA[r] * (double)rA[c];
+                for (int c = rr; c < 6; c++) row[k++] = (double)rA[rr] * (double)rA[c];
 #pragma unroll
-            for (int r = 0; r < 6; r++) acc[21 + r] = (double)rA[r] * (double)rB;
-            acc[27] = 1.0;
+            for (int rr = 0; rr < 6; rr++) row[21 + rr] = (double)rA[rr] * (double)rB;
+            row[27] = 1.0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 28; k++) row[k] = 0.0;
         }
     }
-    __shared__ double sred[ICP_BLOCK / 64][28];
-#pragma unroll
-    for (int k = 0; k < 28; k++) { const double v = wave_sum(acc[k]); if (lane_id() == 0) sred[wave_id()][k] = v; }
     __syncthreads();
-    if (threadIdx.x < 28) {
+    if (threadIdx.x < 28) {                     // fixed summation order → bit-reproducible from run to run
         double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < ICP_BLOCK / 64; w++) v += sred[w][threadIdx.x];
-        a.partial[blockIdx.x * 28 + threadIdx.x] = v;
+#pragma unroll 8
+        for (int q = 0; q < ICP_QPB; q++) v += srow[q][threadIdx.x];
+        a.partial[(size_t)blockIdx.x * 28 + threadIdx.x] = v;
     }
 }
 
@@ -482,16 +513,27 @@ __device__ void eig6_sym(float A[6][6], float W[6], float V[6][6])
     }
 }
 
-__global__ __launch_bounds__(64) void icp_solve_kernel(IcpArgs a, int iter)
+constexpr int SOLVE_THREADS = 1024;
+__global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int iter)
 {
     IcpState& s = *a.st;
     if (s.done) return;
+    __shared__ double part[SOLVE_THREADS / 32][28];
     __shared__ double sums[28];
     const int Q = a.nq[0] + a.nq[1];
-    const int nb = (Q + ICP_BLOCK - 1) / ICP_BLOCK;
+    const int nb = (Q + ICP_QPB - 1) / ICP_QPB;
+    {   // 32 groups x 28 columns, each group strides over the workgroup partials; then a fixed-order combine
+        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+        if (k < 28) {
+            double v = 0.0;
+            for (int b = g; b < nb; b += SOLVE_THREADS / 32) v += a.partial[(size_t)b * 28 + k];
+            part[g][k] = v;
+        }
+    }
+    __syncthreads();
     if (threadIdx.x < 28) {
         double v = 0.0;
-        for (int b = 0; b < nb; b++) v += a.partial[b * 28 + threadIdx.x];      // fixed order → run-to-run reproducible
+        for (int g = 0; g < SOLVE_THREADS / 32; g++) v += part[g][threadIdx.x];
         sums[threadIdx.x] = v;
     }
     __syncthreads();
@@ -626,12 +668,21 @@ __global__ __launch_bounds__(256) void transform_dev_pose_kernel(const lvi_pt* i
 __global__ __launch_bounds__(ICP_BLOCK) void residual_debug_kernel(IcpArgs a, int which, const IcpPose* pose)
 {
     const int n = a.nq[which];
-    const int t = blockIdx.x * ICP_BLOCK + threadIdx.x;
-    if (t >= n) return;
-    lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
-    const bool ok = which == 0 ? corner_residual(a, pose->A, a.q[0][t], cf) : surf_residual(a, pose->A, a.q[1][t], cf);
-    a.flag[t] = ok ? 1 : 0;
-    a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+    const int ql = threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
+    const int t = blockIdx.x * ICP_QPB + ql;
+    if (blockIdx.x * ICP_QPB >= n) return;
+    const bool active = t < n;
+    lvi_pt ori = {0.f, 0.f, 0.f, 0.f};
+    if (active) ori = a.q[which][t];
+    const lvi_pt sel = to_map(pose->A, ori);
+    Knn5 r;
+    if (active) knn5_search_group(*a.meta[which], a.cell_start[which], a.sorted[which], sel.x, sel.y, sel.z, sub, r);
+    if (active && sub == 0) {
+        lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
+        const bool ok = which == 0 ? corner_residual(a, sel, r, cf) : surf_residual(a, ori, sel, r, cf);
+        a.flag[t] = ok ? 1 : 0;
+        a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+    }
 }
 
 __global__ void set_dyn2_kernel(VoxSegDyn* dyn, int n0, int n1)
@@ -690,14 +741,14 @@ void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_i
                                                        pose_init[0], pose_init[1], pose_init[2], pose_init[3], pose_init[4], pose_init[5], d.have_map ? 1 : 0));
     for (int it = 0; it < a.max_iters; it++) {
         LVI_LAUNCH(d.ctx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL(icp_residual_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a));
-        LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, d.ctx.stream, a, it));
+        LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, d.ctx.stream, a, it));
     }
     LVI_LAUNCH(d.ctx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a));
 }
 
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd)
 {
-    hipLaunchKernelGGL(knn_debug_kernel, dim3(div_up(std::max(nq, 1), 256)), dim3(256), 0, d.ctx.stream,
+    hipLaunchKernelGGL(knn_debug_kernel, dim3(div_up(std::max(nq, 1), 256 / 8)), dim3(256), 0, d.ctx.stream,
                        d.grid[which].meta, d.grid[which].cell_start, d.grid[which].sorted, d_queries, nq, d_idx, d_sqd);
     LVI_HIP(hipGetLastError());
 }

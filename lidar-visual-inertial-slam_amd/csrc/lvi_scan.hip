@@ -209,20 +209,24 @@ __global__ __launch_bounds__(256) void feat_smooth_kernel(FeatArgs a)
 // Ties in curvature: the reference's std::sort order is unspecified; here larger index first for
 // corners, smaller index first for the surf walk.
 // ---------------------------------------------------------------------------------------------
-constexpr int FEAT_THREADS = 1024;
+constexpr int FEAT_THREADS = 512;
 enum : uint8_t { ST_N = 0, ST_U = 1, ST_L = 2 };
 
 __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
 {
     __shared__ float s_curv[FEAT_SEG_CAP + 16];
     __shared__ uint8_t s_pick[FEAT_SEG_CAP + 16], s_brk[FEAT_SEG_CAP + 16], s_state[FEAT_SEG_CAP + 16];
-    __shared__ unsigned long long s_wbest[FEAT_THREADS / 64];
+    __shared__ unsigned long long s_key[FEAT_SEG_CAP];        // corner candidates: (curvature bits << 32) | local index
+    __shared__ unsigned short s_sorted[FEAT_SEG_CAP];         // candidates by descending key
+    __shared__ int s_ws[FEAT_THREADS / 64 + 2];
     __shared__ int s_any;
 
     const int ring = blockIdx.x;
     const int n = *a.d_n;
     const int tid = threadIdx.x;
     const int fresh = *a.d_fresh;
+    volatile uint8_t* v_pick = s_pick;
+    volatile uint8_t* v_state = s_state;
 
     for (int sec = 0; sec < 6; sec++) {
         const int sR = a.startR[ring], eR = a.endR[ring];
@@ -250,48 +254,60 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         // candidate in either walk; k = 4 can only be sp of ring 0, sector 0.
         const int jlo = (sp == 4 && ring == 0 && sec == 0) ? 6 : 5;      // first candidate local index
         const int jhi = 5 + (ep - sp);                                    // local index of ep
-        // ---- corners
-        int taken = 0;
-        for (int round = 0; round <= CORNERS_PER_SECTOR; round++) {
-            if (taken >= CORNERS_PER_SECTOR) break;
-            int win = -1;
-            if (round == 0) {
-                // position ep is outside the sorted range and is visited first (:171,174)
-                if (jhi >= jlo && s_pick[jhi] == 0 && s_curv[jhi] > a.edgeThreshold) win = jhi;
-            }
-            if (win < 0) {
-                unsigned long long best = 0ull;
-                for (int j = jlo + tid; j < jhi; j += FEAT_THREADS) {
-                    const float c = s_curv[j];
-                    if (s_pick[j] == 0 && c > a.edgeThreshold) {
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(c) << 32) | (unsigned)(j + 1);
-                        best = key > best ? key : best;
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(best, o, 64); best = t > best ? t : best; }
-                if (lane_id() == 0) s_wbest[wave_id()] = best;
-                __syncthreads();
-                unsigned long long bb = 0ull;
-#pragma unroll
-                for (int q = 0; q < FEAT_THREADS / 64; q++) { const unsigned long long t = s_wbest[q]; bb = t > bb ? t : bb; }
-                win = (bb == 0ull) ? -1 : (int)(bb & 0xFFFFFFFFull) - 1;
-            }
-            if (win < 0) break;                                          // uniform
-            if (tid == 0) { out_idx[taken] = k0 + win; a.label[k0 + win] = 1; s_pick[win] = 1; }
-            if (tid >= 1 && tid <= 5) {                                  // +l marks
-                bool ok = true;
-                for (int l = 1; l <= tid; l++) ok = ok && !s_brk[win + l];
-                if (ok) s_pick[win + tid] = 1;
-            } else if (tid >= 6 && tid <= 10) {                          // -l marks
-                const int m = tid - 5; bool ok = true;
-                for (int l = 1; l <= m; l++) ok = ok && !s_brk[win - l + 1];
-                if (ok) s_pick[win - m] = 1;
-            }
-            taken++;
-            __syncthreads();
+        // ---- corners.  The reference sorts [sp,ep) by curvature and walks ep, then the sorted range from
+        // the top, taking a point if it is still unpicked (max 40) and marking its +-5 neighbours.
+        // Here: compact the candidates (unpicked, curvature > edgeThreshold), rank-sort them in LDS, and
+        // let ONE wavefront do the greedy walk, 64 candidates at a time, conflicts resolved by ballot.
+        int ncand = 0;
+        for (int c0 = jlo; c0 < jhi; c0 += FEAT_THREADS) {
+            const int j = c0 + tid;
+            const bool cand = j < jhi && s_pick[j] == 0 && s_curv[j] > a.edgeThreshold;
+            int tot;
+            const int pos = ncand + block_excl_scan<FEAT_THREADS>(cand ? 1 : 0, s_ws, &tot);
+            if (cand) s_key[pos] = ((unsigned long long)__float_as_uint(s_curv[j]) << 32) | (unsigned)j;
+            ncand += tot;
         }
-        if (tid == 0) a.sector_cnt[ring * 6 + sec] = taken;
+        __syncthreads();
+        for (int i = tid; i < ncand; i += FEAT_THREADS) {
+            const unsigned long long mine = s_key[i];
+            int rank = 0;
+            for (int q = 0; q < ncand; q++) rank += (s_key[q] > mine) ? 1 : 0;     // keys are unique (index in the low word)
+            s_sorted[rank] = (unsigned short)(mine & 0xFFFFu);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int l = tid;
+            int taken = 0;
+            // one "take": record, label, mark +-5 unless a column break intervenes
+            auto take = [&](int win) {
+                if (l == 0) { out_idx[taken] = k0 + win; a.label[k0 + win] = 1; v_pick[win] = 1; }
+                if (l >= 1 && l <= 5) {
+                    bool ok = true;
+                    for (int q = 1; q <= l; q++) ok = ok && !s_brk[win + q];
+                    if (ok) v_pick[win + l] = 1;
+                } else if (l >= 6 && l <= 10) {
+                    const int m = l - 5; bool ok = true;
+                    for (int q = 1; q <= m; q++) ok = ok && !s_brk[win - q + 1];
+                    if (ok) v_pick[win - m] = 1;
+                }
+                taken++;
+            };
+            // position ep is outside the sorted range and is visited first (:171,174)
+            if (jhi >= jlo && v_pick[jhi] == 0 && s_curv[jhi] > a.edgeThreshold) take(jhi);
+            for (int base = 0; base < ncand && taken < CORNERS_PER_SECTOR; base += 64) {
+                const int j = (base + l < ncand) ? (int)s_sorted[base + l] : -1;
+                bool alive = j >= 0 && v_pick[j] == 0;
+                uint64_t m = __ballot(alive);
+                while (m && taken < CORNERS_PER_SECTOR) {
+                    const int first = __ffsll((long long)m) - 1;
+                    const int win = __shfl(j, first, 64);
+                    take(win);
+                    alive = alive && l != first && v_pick[j] == 0;
+                    m = __ballot(alive);
+                }
+            }
+            if (l == 0) a.sector_cnt[ring * 6 + sec] = taken;
+        }
         __syncthreads();
         // ---- first scan of a fresh node: the stale entry {0, ind 0} is the first element of the ascending
         // walk of ring 0 / sector 0; it labels ind 0 and marks picked[1..5] (only 5 is a candidate).
@@ -299,10 +315,10 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             bool ok = true;
             for (int k = 1; k <= 5; k++) ok = ok && (abs(a.col[k] - a.col[k - 1]) <= 10);
             if (ok && a.surfThreshold > 0.f) s_pick[6] = 1;             // local index of k = 5
-            // (marks on k = 1..4 are never read; k = 5 needs all of col[0..5] unbroken)
         }
         __syncthreads();
-        // ---- surf walk as a fixed point
+        // ---- surf walk as a fixed point (ascending curvature, position ep last; a point is labelled iff no
+        // earlier-in-order reachable neighbour is labelled).  Decisions are monotone, so in-place updates are safe.
         for (int j = tid; j < L; j += FEAT_THREADS)
             s_state[j] = (j >= jlo && j <= jhi && s_pick[j] == 0 && s_curv[j] < a.surfThreshold) ? ST_U : ST_N;
         __syncthreads();
@@ -311,26 +327,24 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             __syncthreads();
             bool mine = false;
             for (int j = jlo + tid; j <= jhi; j += FEAT_THREADS) {
-                if (((volatile uint8_t*)s_state)[j] != ST_U) continue;
+                if (v_state[j] != ST_U) continue;
                 const float cj = s_curv[j];
                 bool blocked = false, wait = false;
-                // neighbours reachable without crossing a column break, that come earlier in the walk
                 for (int dir = 0; dir < 2; dir++) {
-                    for (int l = 1; l <= 5; l++) {
-                        const int x = dir ? j + l : j - l;
-                        if (dir ? s_brk[j + l] : s_brk[j - l + 1]) break;
+                    for (int q = 1; q <= 5; q++) {
+                        const int x = dir ? j + q : j - q;
+                        if (dir ? s_brk[j + q] : s_brk[j - q + 1]) break;
                         if (x < jlo || x > jhi) continue;
-                        const uint8_t sx = ((volatile uint8_t*)s_state)[x];
+                        const uint8_t sx = v_state[x];
                         if (sx == ST_N) continue;
                         const float cx = s_curv[x];
-                        // position ep is walked last; otherwise ascending curvature, ties by index
                         const bool earlier = (x == jhi) ? false : (j == jhi) ? true : (cx < cj || (cx == cj && x < j));
                         if (!earlier) continue;
                         if (sx == ST_L) blocked = true; else wait = true;
                     }
                 }
-                if (blocked) ((volatile uint8_t*)s_state)[j] = ST_N;
-                else if (!wait) ((volatile uint8_t*)s_state)[j] = ST_L;
+                if (blocked) v_state[j] = ST_N;
+                else if (!wait) v_state[j] = ST_L;
                 else mine = true;
             }
             if (mine) s_any = 1;
@@ -339,13 +353,13 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             __syncthreads();
             if (!any) break;
         }
-        // ---- apply labels and their ±5 marks, write back
+        // ---- apply labels and their +-5 marks, write back
         for (int j = jlo + tid; j <= jhi; j += FEAT_THREADS) {
             if (s_state[j] != ST_L) continue;
             a.label[k0 + j] = -1;
-            s_pick[j] = 1;
-            for (int l = 1; l <= 5; l++) { if (s_brk[j + l]) break; s_pick[j + l] = 1; }
-            for (int l = 1; l <= 5; l++) { if (s_brk[j - l + 1]) break; s_pick[j - l] = 1; }
+            v_pick[j] = 1;
+            for (int q = 1; q <= 5; q++) { if (s_brk[j + q]) break; v_pick[j + q] = 1; }
+            for (int q = 1; q <= 5; q++) { if (s_brk[j - q + 1]) break; v_pick[j - q] = 1; }
         }
         __syncthreads();
         for (int j = tid; j < L; j += FEAT_THREADS) {
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             a.picked[k] = s_pick[j];
             if (j >= 5 && j <= jhi) a.surfmask[k] = (a.label[k] <= 0) ? 1 : 0;       // :231-236 (label[k] <= 0)
         }
+        __threadfence_block();
         __syncthreads();
     }
     if (ring == 0 && tid == 0 && n > 16) *a.d_fresh = 0;
@@ -452,7 +467,7 @@ void lidar_allocate(LidarDev& d)
     d.map_cap = std::max(d.P.max_map_points, 64);
     d.nblk_org = div_up(d.raw_cap, ORG_TILE);
     d.max_cells = 1 << 24;
-    d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK);
+    d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / 8);      // 8 lanes per query (KNN_G)
     ArenaSizer sz;
     layout(sz, d);
     d.arena.init(sz.used + (1 << 20));

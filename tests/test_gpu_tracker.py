@@ -1,0 +1,144 @@
+"""GPU tier (-m gpu): HIP LK + GFTT against the CPU oracle (restated OpenCV algorithms) through the
+same C-ABI.  LK patch arithmetic is fixed point with exact integer sums → positions, status and err
+must be bit-exact; the min-eigenvalue map follows a fixed f32 operation order → bit-exact; GFTT
+output coordinates are integers → exact.  PARITY UNPINNED (OpenCV is not in the reference tree)."""
+import numpy as np
+import pytest
+
+from helpers import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames(pkg):
+    S = pkg.synth
+    w, h = 320, 240
+    img0 = S.make_texture(w, h, 4242)
+    Hm = S.small_motion_homography(w, h, 7, max_px=5.0)
+    return dict(w=w, h=h, img0=img0, img1=S.warp_homography(img0, Hm), H=Hm)
+
+
+@pytest.fixture()
+def pair(pkg, oracle, hip):
+    kw = dict(max_width=1280, max_height=720, max_features=1024)
+    o = pkg.TrackerHotpath(oracle, **kw)
+    g = pkg.TrackerHotpath(hip, **kw)
+    yield o, g
+    o.close(); g.close()
+
+
+def test_pyramid_bit_exact(pkg, pair, frames):
+    A = pkg._abi
+    o, g = pair
+    for t in (o, g):
+        t.push_image(frames["img0"])
+    for what in (A.TDBG_PYRAMID_L1, A.TDBG_PYRAMID_L2, A.TDBG_PYRAMID_L3):
+        np.testing.assert_array_equal(o.debug_get(what, np.uint8), g.debug_get(what, np.uint8))
+
+
+def test_mineig_map_and_gftt_exact(pkg, pair, frames):
+    A = pkg._abi
+    o, g = pair
+    po = o.good_features(frames["img0"], 150, 0.01, 20.0)
+    pg = g.good_features(frames["img0"], 150, 0.01, 20.0)
+    eo, eg = o.debug_get(A.TDBG_MINEIG, np.float32), g.debug_get(A.TDBG_MINEIG, np.float32)
+    np.testing.assert_array_equal(bits(eo), bits(eg))
+    assert o.debug_get(A.TDBG_GFTT_NCAND, np.int32)[0] == g.debug_get(A.TDBG_GFTT_NCAND, np.int32)[0]
+    assert len(po) > 40
+    np.testing.assert_array_equal(po, pg)
+    # min distance holds
+    d = np.linalg.norm(pg[:, None, :] - pg[None, :, :], axis=2) + np.eye(len(pg)) * 1e9
+    assert d.min() >= 20.0
+
+
+def test_gftt_mask_quota_and_small_distance(pkg, pair, frames):
+    o, g = pair
+    mask = np.full((frames["h"], frames["w"]), 255, np.uint8)
+    mask[:, : frames["w"] // 2] = 0
+    for quota, md in ((30, 20.0), (500, 6.0), (0, 12.0), (25, 0.5)):
+        po = o.good_features(frames["img0"], quota, 0.01, md, mask)
+        pg = g.good_features(frames["img0"], quota, 0.01, md, mask)
+        np.testing.assert_array_equal(po, pg)
+        assert (pg[:, 0] >= frames["w"] // 2).all()
+        if quota > 0:
+            assert len(pg) <= quota
+
+
+def test_lk_bit_exact_and_tracks_the_motion(pkg, pair, frames):
+    S = pkg.synth
+    o, g = pair
+    pts = g.good_features(frames["img0"], 150, 0.01, 12.0)
+    assert len(pts) >= 60
+    xo, so, eo = o.lk_track(frames["img0"], frames["img1"], pts)
+    xg, sg, eg = g.lk_track(frames["img0"], frames["img1"], pts)
+    np.testing.assert_array_equal(so, sg)
+    np.testing.assert_array_equal(bits(xo[so == 1]), bits(xg[sg == 1]))
+    np.testing.assert_array_equal(bits(eo[so == 1]), bits(eg[sg == 1]))
+    # ground truth: the homography the second frame was rendered with
+    gt = S.apply_homography(frames["H"], pts)
+    ok = sg == 1
+    assert ok.mean() > 0.9
+    e = np.linalg.norm(xg[ok] - gt[ok], axis=1)
+    assert np.median(e) < 0.1 and np.quantile(e, 0.9) < 0.5, (np.median(e), np.quantile(e, 0.9))
+
+
+def test_lk_border_and_degenerate_points(pkg, pair, frames):
+    o, g = pair
+    w, h = frames["w"], frames["h"]
+    flat = np.full((h, w), 127, np.uint8)
+    pts = np.array([[0.0, 0.0], [w - 1.0, h - 1.0], [-40.0, 10.0], [w + 40.0, 20.0], [3.5, h - 2.25], [w / 2, h / 2], [10.75, 10.25]], np.float32)
+    for a, b in ((frames["img0"], frames["img1"]), (flat, flat)):
+        xo, so, eo = o.lk_track(a, b, pts)
+        xg, sg, eg = g.lk_track(a, b, pts)
+        np.testing.assert_array_equal(so, sg)
+        np.testing.assert_array_equal(bits(xo[so == 1]), bits(xg[sg == 1]))
+    assert sg.sum() == 0                       # textureless image: minEig below threshold everywhere
+    # n = 0
+    x, s, e = g.lk_track(frames["img0"], frames["img1"], np.zeros((0, 2), np.float32))
+    assert len(x) == 0
+
+
+def test_staged_tracking_over_frames(pkg, pair, frames):
+    """FeatureTracker::readImage rotation: forw becomes cur on the next push (feature_tracker.cpp:200-204)"""
+    S = pkg.synth
+    o, g = pair
+    w, h = frames["w"], frames["h"]
+    seq = [frames["img0"]] + [S.warp_homography(frames["img0"], S.small_motion_homography(w, h, 50 + i, 4.0)) for i in range(3)]
+    pts = g.good_features(seq[0], 100, 0.01, 15.0)
+    res = []
+    for t in (o, g):
+        t.push_image(seq[0])
+        p = pts.copy(); out = []
+        for f in seq[1:]:
+            t.push_image(f); t.set_points(p); t.run_lk()
+            xy, st, err = t.get_lk()
+            out.append((xy.copy(), st.copy()))
+            p = xy[st == 1]
+        res.append(out)
+    for (xo, so), (xg, sg) in zip(*res):
+        np.testing.assert_array_equal(so, sg)
+        np.testing.assert_array_equal(bits(xo[so == 1]), bits(xg[sg == 1]))
+
+
+def test_full_size_1280x720(pkg, oracle, hip):
+    """BASELINE config 4: 1280x720, 150 features, 4 pyramid levels"""
+    S = pkg.synth
+    w, h = 1280, 720
+    img0 = S.make_texture(w, h, 4242)
+    Hm = S.small_motion_homography(w, h, 101)
+    img1 = S.warp_homography(img0, Hm)
+    o = pkg.TrackerHotpath(oracle, max_width=w, max_height=h)
+    g = pkg.TrackerHotpath(hip, max_width=w, max_height=h)
+    po = o.good_features(img0, 150, 0.01, 20.0)
+    pg = g.good_features(img0, 150, 0.01, 20.0)
+    np.testing.assert_array_equal(po, pg)
+    assert len(pg) == 150
+    xo, so, eo = o.lk_track(img0, img1, pg)
+    xg, sg, eg = g.lk_track(img0, img1, pg)
+    np.testing.assert_array_equal(so, sg)
+    np.testing.assert_array_equal(bits(xo[so == 1]), bits(xg[sg == 1]))
+    gt = S.apply_homography(Hm, pg)
+    e = np.linalg.norm(xg[sg == 1] - gt[sg == 1], axis=1)
+    assert (sg == 1).mean() > 0.9 and np.median(e) < 0.1
+    o.close(); g.close()
