@@ -111,12 +111,12 @@ def main():
 
     def step(i):
         k = i % args.pool
+        if not args.frozen_map:
+            g.map_build()                                             # own stream: overlaps the scan-side stages
         g.scan_upload_device(d_scans[k].data_ptr(), args.n_raw)       # D2D, 2 MB
         g.scan_organize()
         g.scan_extract()
         g.scan_downsample()
-        if not args.frozen_map:
-            g.map_build()
         g.scan_match_async(guesses[k], d_rec[i].data_ptr())
         g.sync()
         if world > 1:

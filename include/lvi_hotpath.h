@@ -213,7 +213,9 @@ enum {
     LVI_DBG_VOXEL_CELLS    = 7,   /* i32[V]   distinct idx, ascending = output order, same call */
     LVI_DBG_VOXEL_COUNTS   = 8,   /* i32[V]   points per output voxel, same call */
     LVI_DBG_ICP_JTJ        = 9,   /* f32[iters*27] 21 upper-triangular AtA + 6 AtB per iteration */
-    LVI_DBG_ICP_POSE_TRACE = 10   /* f32[(iters+1)*6] transformTobeMapped before iteration k (and after the last) */
+    LVI_DBG_ICP_POSE_TRACE = 10,  /* f32[(iters+1)*6] transformTobeMapped before iteration k (and after the last) */
+    LVI_DBG_FEAT_CYCLES    = 11   /* i64[8] [hip only] shader cycles of ring 0's sector kernel by phase: load, compact, rank, walk,
+                                     fixed-point set-up, fixed-point rounds, number of rounds, apply+store */
 };
 int32_t lvi_debug_get(lvi_lidar *h, int32_t what, void *dst, int64_t capacity_bytes, int64_t *n_bytes);
 

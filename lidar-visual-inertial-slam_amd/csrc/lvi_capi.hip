@@ -76,16 +76,22 @@ int32_t guarded(lvi_lidar* h, F&& f)
     }
 }
 
-void sync(LidarDev& d) { LVI_HIP(hipStreamSynchronize(d.ctx.stream)); }
+void sync(LidarDev& d)
+{
+    if (d.map_pending) join_map(d);
+    LVI_HIP(hipStreamSynchronize(d.ctx.stream));
+}
 
 template <class T>
 void d2h(LidarDev& d, T* dst, const T* src, size_t n)
 {
+    join_map(d);       // a pending map build (second stream) must be visible to anything the host reads or rewrites
     if (n) LVI_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, d.ctx.stream));
 }
 template <class T>
 void h2d(LidarDev& d, T* dst, const T* src, size_t n)
 {
+    join_map(d);
     if (n) LVI_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, d.ctx.stream));
 }
 
@@ -175,7 +181,10 @@ int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** 
     h->d.P = *p; h->d.device = device;
     int32_t st = guarded(h, [&]() -> int32_t {
         LVI_HIP(hipStreamCreateWithFlags(&h->d.ctx.stream, hipStreamNonBlocking));
-        h->d.ctx.prof = &h->d.prof;
+        LVI_HIP(hipStreamCreateWithFlags(&h->d.ctx2.stream, hipStreamNonBlocking));
+        LVI_HIP(hipEventCreateWithFlags(&h->d.evMain, hipEventDisableTiming));
+        LVI_HIP(hipEventCreateWithFlags(&h->d.evMap, hipEventDisableTiming));
+        h->d.ctx.prof = &h->d.prof; h->d.ctx2.prof = &h->d.prof;
         lidar_allocate(h->d);
         return LVI_OK;
     });
@@ -189,10 +198,14 @@ void lvi_lidar_destroy(lvi_lidar* h)
     if (!h) return;
     (void)hipSetDevice(h->d.device);
     if (h->d.ctx.stream) { (void)hipStreamSynchronize(h->d.ctx.stream); }
+    if (h->d.ctx2.stream) { (void)hipStreamSynchronize(h->d.ctx2.stream); }
     h->d.prof.collect();
     h->d.arena.release();
     if (h->d.h_icp) (void)hipHostFree(h->d.h_icp);
     if (h->d.ctx.stream) (void)hipStreamDestroy(h->d.ctx.stream);
+    if (h->d.ctx2.stream) (void)hipStreamDestroy(h->d.ctx2.stream);
+    if (h->d.evMain) (void)hipEventDestroy(h->d.evMain);
+    if (h->d.evMap) (void)hipEventDestroy(h->d.evMap);
     delete h;
 }
 
@@ -236,6 +249,7 @@ int32_t lvi_map_upload_device(lvi_lidar* h, const void* c, int32_t nc, const voi
     if (nc > h->d.map_cap || ns > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
+        join_map(d);
         if (nc) LVI_HIP(hipMemcpyAsync(d.mapCornerRaw, c, sizeof(lvi_pt) * (size_t)nc, hipMemcpyDeviceToDevice, d.ctx.stream));
         if (ns) LVI_HIP(hipMemcpyAsync(d.mapSurfRaw, s, sizeof(lvi_pt) * (size_t)ns, hipMemcpyDeviceToDevice, d.ctx.stream));
         d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.have_map = false;
@@ -489,6 +503,11 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
                 if (!need_feat()) return fail(LVI_ERR_STATE, "stage not run");
                 const int n = read_int(d, d.d_ncorner);
                 std::vector<int32_t> v(n); d2h(d, v.data(), d.corner_idx, (size_t)n); sync(d);
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
+            case LVI_DBG_FEAT_CYCLES: {
+                if (!need_feat()) return fail(LVI_ERR_STATE, "stage not run");
+                std::vector<long long> v(8); d2h(d, v.data(), d.d_feat_cycles, 8); sync(d);
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
             case LVI_DBG_VOXEL_KEYS: return dbg_out(h->vkeys, 0, dst, cap, n_bytes);

@@ -233,42 +233,91 @@ __device__ void eig3_sym(float a11, float a12, float a13, float a22, float a23, 
     for (int k = 0; k < 3; k++) v0[k] = i0 == 0 ? V[k][0] : (i0 == 1 ? V[k][1] : V[k][2]);
 }
 
-// least squares of the 5x3 system A x = b by Householder QR with column pivoting (f32)
-__device__ void lstsq_5x3(float A[5][3], float b[5], float x[3])
+// least squares of the 5x3 system A x = b by Householder QR with column pivoting (f32).
+// Column-major registers and compile-time indices only (a runtime-indexed private array is demoted
+// to LDS/scratch by hipcc and made this the slowest part of the residual kernel).
+__device__ __forceinline__ void lstsq_5x3(float A[5][3], float b[5], float x[3])
 {
-    int perm[3] = {0, 1, 2};
+    float c[3][5];                       // c[col][row]
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 5; i++) c[j][i] = A[i][j];
+    int p0 = 0, p1 = 1, p2 = 2;          // perm: column k of the factorisation is original column p_k
     int rank = 3;
     float thr0 = 0.f;
-    for (int j = 0; j < 3; j++) { float s = 0.f; for (int i = 0; i < 5; i++) s += A[i][j] * A[i][j]; thr0 = fmaxf(thr0, sqrtf(s)); }
+#pragma unroll
+    for (int j = 0; j < 3; j++) { float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; i++) s += c[j][i] * c[j][i];
+        thr0 = fmaxf(thr0, sqrtf(s)); }
     const float thr = (thr0 * 1.1920929e-7f) * (thr0 * 1.1920929e-7f) / 5.f;
+    float diag[3];
+#pragma unroll
     for (int k = 0; k < 3; k++) {
-        int big = k; float bigsq = -1.f;
-        for (int j = k; j < 3; j++) { float s = 0.f; for (int i = k; i < 5; i++) s += A[i][j] * A[i][j]; if (s > bigsq) { bigsq = s; big = j; } }
+        // largest remaining column norm (rows k..4)
+        float nrm[3] = {-1.f, -1.f, -1.f};
+#pragma unroll
+        for (int j = 0; j < 3; j++) if (j >= k) { float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (i >= k) s += c[j][i] * c[j][i];
+            nrm[j] = s; }
+        int big = k; float bigsq = nrm[k];
+#pragma unroll
+        for (int j = 0; j < 3; j++) if (j > k && nrm[j] > bigsq) { bigsq = nrm[j]; big = j; }
         if (rank == 3 && bigsq < thr * (float)(5 - k)) rank = k;
-        if (big != k) { for (int i = 0; i < 5; i++) { const float t = A[i][k]; A[i][k] = A[i][big]; A[i][big] = t; } const int t = perm[k]; perm[k] = perm[big]; perm[big] = t; }
-        const float c0 = A[k][k];
-        float tail = 0.f; for (int i = k + 1; i < 5; i++) tail += A[i][k] * A[i][k];
+#pragma unroll
+        for (int j = 0; j < 3; j++) if (j > k && big == j) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) { const float t = c[k][i]; c[k][i] = c[j][i]; c[j][i] = t; }
+            // swap perm[k] and perm[j]
+            int pk = (k == 0) ? p0 : (k == 1 ? p1 : p2), pj = (j == 1) ? p1 : p2;
+            if (k == 0) p0 = pj; else if (k == 1) p1 = pj;
+            if (j == 1) p1 = pk; else p2 = pk;
+        }
+        const float c0 = c[k][k];
+        float tail = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (i > k) tail += c[k][i] * c[k][i];
         float tau, beta;
-        if (tail <= 1.17549435e-38f) { tau = 0.f; beta = c0; for (int i = k + 1; i < 5; i++) A[i][k] = 0.f; }
-        else {
+        if (tail <= 1.17549435e-38f) {
+            tau = 0.f; beta = c0;
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (i > k) c[k][i] = 0.f;
+        } else {
             beta = sqrtf(c0 * c0 + tail); if (c0 >= 0.f) beta = -beta;
-            for (int i = k + 1; i < 5; i++) A[i][k] /= (c0 - beta);
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (i > k) c[k][i] /= (c0 - beta);
             tau = (beta - c0) / beta;
         }
-        A[k][k] = beta;
-        for (int j = k + 1; j < 3; j++) {
-            float s = 0.f; for (int i = k + 1; i < 5; i++) s += A[i][k] * A[i][j];
-            s += A[k][j]; s *= tau; A[k][j] -= s;
-            for (int i = k + 1; i < 5; i++) A[i][j] -= s * A[i][k];
+        diag[k] = beta;
+#pragma unroll
+        for (int j = 0; j < 3; j++) if (j > k) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (i > k) s += c[k][i] * c[j][i];
+            s += c[j][k]; s *= tau; c[j][k] -= s;
+#pragma unroll
+            for (int i = 0; i < 5; i++) if (i > k) c[j][i] -= s * c[k][i];
         }
-        float s = 0.f; for (int i = k + 1; i < 5; i++) s += A[i][k] * b[i];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (i > k) s += c[k][i] * b[i];
         s += b[k]; s *= tau; b[k] -= s;
-        for (int i = k + 1; i < 5; i++) b[i] -= s * A[i][k];
+#pragma unroll
+        for (int i = 0; i < 5; i++) if (i > k) b[i] -= s * c[k][i];
     }
-    float c[3] = {0.f, 0.f, 0.f};
-    for (int i = rank - 1; i >= 0; i--) { float s = b[i]; for (int j = i + 1; j < rank; j++) s -= A[i][j] * c[j]; c[i] = s / A[i][i]; }
+    // back substitution on the leading rank x rank block: R(i,j) = c[j][i] for j > i, R(i,i) = diag[i]
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    if (rank >= 3) y2 = b[2] / diag[2];
+    if (rank >= 2) y1 = (b[1] - (rank >= 3 ? c[2][1] * y2 : 0.f)) / diag[1];
+    if (rank >= 1) y0 = (b[0] - (rank >= 2 ? c[1][0] * y1 : 0.f) - (rank >= 3 ? c[2][0] * y2 : 0.f)) / diag[0];
     x[0] = x[1] = x[2] = 0.f;
-    for (int i = 0; i < rank; i++) x[perm[i]] = c[i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float v = (p0 == j ? y0 : 0.f) + (p1 == j ? y1 : 0.f) + (p2 == j ? y2 : 0.f);
+        x[j] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- residuals
@@ -454,26 +503,37 @@ __global__ void icp_init_kernel(IcpArgs a, float t0, float t1, float t2, float t
 // Householder QR solve of the 6x6 system (cv::solve DECOMP_QR, :1260), f32
 __device__ bool solve6_qr(float A[6][6], float b[6])
 {
-    float vl[6], hF[6];
+    // fully unrolled: every index is a compile-time constant, so A, b and the Householder vector stay in registers
+#pragma unroll
     for (int l = 0; l < 6; l++) {
+        float vl[6];
         float nrm = 0.f;
-        for (int i = l; i < 6; i++) { vl[i] = A[i][l]; nrm += vl[i] * vl[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i >= l) { vl[i] = A[i][l]; nrm += vl[i] * vl[i]; }
         const float t0 = vl[l];
         vl[l] = vl[l] + (vl[l] >= 0.f ? 1.f : -1.f) * sqrtf(nrm);
         nrm = sqrtf(nrm + vl[l] * vl[l] - t0 * t0);
         if (nrm == 0.f) return false;
-        for (int i = l; i < 6; i++) vl[i] /= nrm;
-        for (int j = l; j < 6; j++) {
-            float s = 0.f; for (int i = l; i < 6; i++) s += vl[i] * A[i][j];
-            for (int i = l; i < 6; i++) A[i][j] -= 2 * vl[i] * s;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i >= l) vl[i] /= nrm;
+#pragma unroll
+        for (int j = 0; j < 6; j++) if (j >= l) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; i++) if (i >= l) s += vl[i] * A[i][j];
+#pragma unroll
+            for (int i = 0; i < 6; i++) if (i >= l) A[i][j] -= 2 * vl[i] * s;
         }
-        float s = 0.f; for (int i = l; i < 6; i++) s += vl[i] * b[i];
-        for (int i = l; i < 6; i++) b[i] -= 2 * vl[i] * s;
-        hF[l] = 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i >= l) s += vl[i] * b[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i >= l) b[i] -= 2 * vl[i] * s;
     }
-    (void)hF;
+#pragma unroll
     for (int i = 5; i >= 0; i--) {
-        for (int j = 5; j > i; j--) b[i] -= b[j] * A[i][j];
+#pragma unroll
+        for (int j = 5; j >= 0; j--) if (j > i) b[i] -= b[j] * A[i][j];
         if (fabsf(A[i][i]) < 1.1920929e-6f) return false;
         b[i] /= A[i][i];
     }
@@ -577,8 +637,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int
             for (int r = 0; r < 6; r++) { double acc = 0; for (int k = 0; k < 6; k++) acc += (double)matP[r][k] * (double)X2[k]; X[r] = (float)acc; }
         }
         for (int r = 0; r < 6; r++) s.pose.T[r] += X[r];
-        const double dR = sqrt(pow((double)(X[0] * 57.29578f), 2.0) + pow((double)(X[1] * 57.29578f), 2.0) + pow((double)(X[2] * 57.29578f), 2.0));
-        const double dT = sqrt(pow((double)(X[3] * 100), 2.0) + pow((double)(X[4] * 100), 2.0) + pow((double)(X[5] * 100), 2.0));
+        // pow(x, 2) of the reference is the correctly rounded double square
+        const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+        const double u0 = (double)(X[3] * 100), u1 = (double)(X[4] * 100), u2 = (double)(X[5] * 100);
+        const double dR = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+        const double dT = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
         const float deltaR = (float)dR, deltaT = (float)dT;
         if (deltaR < 0.05 && deltaT < 0.05) {                                    // :1309
             s.converged = 1;
@@ -707,12 +770,25 @@ IcpArgs icp_args(LidarDev& d)
 
 }  // namespace
 
+void join_map(LidarDev& d)
+{
+    if (d.map_pending) { LVI_HIP(hipStreamWaitEvent(d.ctx.stream, d.evMap, 0)); d.map_pending = false; }
+}
+
+// The map build does not depend on the current scan, so it runs on its own stream and overlaps the
+// scan-side stages (organise / sector kernel / scan voxel grids, which occupy only a few CUs); the
+// main stream joins it right before scan matching.
 void stage_map_build(LidarDev& d)
 {
+    const Ctx& cx = d.ctx2;
+    // everything already enqueued on the main stream (map upload, the previous scan's GN loop reading the
+    // previous index) must finish before the map buffers are rewritten
+    LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));
+    LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
     // raw map counts are host-known here; the voxel plan wants them in device memory
-    hipLaunchKernelGGL(set_dyn2_kernel, dim3(1), dim3(1), 0, d.ctx.stream, d.voxMap.d_dyn, d.n_map_corner, d.n_map_surf);
+    hipLaunchKernelGGL(set_dyn2_kernel, dim3(1), dim3(1), 0, cx.stream, d.voxMap.d_dyn, d.n_map_corner, d.n_map_surf);
     const double n = (double)d.n_map_corner + (double)d.n_map_surf;
-    voxel_downsample_batch(d.ctx, d.voxMap, "map", n);
+    voxel_downsample_batch(cx, d.voxMap, "map", n);
 
     GridArgs g{};
     for (int w = 0; w < 2; w++) { g.meta[w] = d.grid[w].meta; g.cell_start[w] = d.grid[w].cell_start; g.sorted[w] = d.grid[w].sorted; }
@@ -722,15 +798,18 @@ void stage_map_build(LidarDev& d)
     g.d_n = d.d_grid_n; g.d_nbits = d.d_grid_nbits; g.cap = d.map_cap; g.max_cells = d.max_cells; g.d_status = d.d_status;
     const double nds = 0.2 * n;      // nominal DS size for byte accounting only
     const dim3 gp(div_up(d.map_cap, 256), 2);
-    LVI_LAUNCH(d.ctx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1), dim3(64), 0, d.ctx.stream, g));
-    LVI_LAUNCH(d.ctx, "grid_keys", 24.0 * nds, hipLaunchKernelGGL(grid_keys_kernel, gp, dim3(256), 0, d.ctx.stream, g));
-    radix_sort_pairs(d.ctx, d.gridSort, d.d_grid_n, d.d_grid_nbits, 3, "grid", nds);
-    LVI_LAUNCH(d.ctx, "grid_fill", 0, hipLaunchKernelGGL(grid_fill_kernel, dim3(2048, 2), dim3(256), 0, d.ctx.stream, g));
-    LVI_LAUNCH(d.ctx, "grid_gather", 36.0 * nds, hipLaunchKernelGGL(grid_gather_kernel, gp, dim3(256), 0, d.ctx.stream, g));
+    LVI_LAUNCH(cx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1), dim3(64), 0, cx.stream, g));
+    LVI_LAUNCH(cx, "grid_keys", 24.0 * nds, hipLaunchKernelGGL(grid_keys_kernel, gp, dim3(256), 0, cx.stream, g));
+    radix_sort_pairs(cx, d.gridSort, d.d_grid_n, d.d_grid_nbits, 3, "grid", nds);
+    LVI_LAUNCH(cx, "grid_fill", 0, hipLaunchKernelGGL(grid_fill_kernel, dim3(2048, 2), dim3(256), 0, cx.stream, g));
+    LVI_LAUNCH(cx, "grid_gather", 36.0 * nds, hipLaunchKernelGGL(grid_gather_kernel, gp, dim3(256), 0, cx.stream, g));
+    LVI_HIP(hipEventRecord(d.evMap, cx.stream));
+    d.map_pending = true;
 }
 
 void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_imu_hint* imu, void* d_record)
 {
+    join_map(d);
     IcpArgs a = icp_args(d);
     a.imu_available = imu ? imu->imu_available : 0;
     a.imu_roll = imu ? imu->imu_roll_init : 0.f;
@@ -748,6 +827,7 @@ void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_i
 
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd)
 {
+    join_map(d);
     hipLaunchKernelGGL(knn_debug_kernel, dim3(div_up(std::max(nq, 1), 256 / 8)), dim3(256), 0, d.ctx.stream,
                        d.grid[which].meta, d.grid[which].cell_start, d.grid[which].sorted, d_queries, nq, d_idx, d_sqd);
     LVI_HIP(hipGetLastError());
@@ -755,6 +835,7 @@ void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_i
 
 void debug_residuals(LidarDev& d, int which, const float pose[6])
 {
+    join_map(d);
     IcpArgs a = icp_args(d);
     hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->pose, pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]);
     hipLaunchKernelGGL(residual_debug_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a, which, &d.icp->pose);

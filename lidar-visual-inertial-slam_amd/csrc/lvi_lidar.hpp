@@ -40,7 +40,10 @@ struct GridIndex {                       // uniform 1 m grid over one DS map (a-
 struct LidarDev {
     lvi_lidar_params P;
     int device = 0;
-    Ctx ctx;
+    Ctx ctx;                                               // scan-side stages and the GN loop
+    Ctx ctx2;                                              // map build (independent of the scan until scan matching)
+    hipEvent_t evMain = nullptr, evMap = nullptr;
+    bool map_pending = false;                              // map build enqueued on ctx2, not yet joined by ctx
     Profiler prof;
     Arena arena;
 
@@ -60,6 +63,7 @@ struct LidarDev {
     lvi_pt* surf = nullptr;                                // concatenated per-ring DS output
     int* d_fresh = nullptr;                                // 1 until the first extract of this handle
     int* d_status = nullptr;
+    long long* d_feat_cycles = nullptr;                    // [8] phase cycle counters of ring 0 (diagnostics)
     VoxelPlan voxRing;                                     // N_SCAN segments, leaf odometrySurfLeafSize
     // ---- scan DS
     lvi_pt *cornerDS = nullptr, *surfDS = nullptr;
@@ -93,6 +97,7 @@ void stage_extract(LidarDev& d);
 void stage_downsample(LidarDev& d);
 // lvi_icp.hip
 void stage_map_build(LidarDev& d);
+void join_map(LidarDev& d);                                // make the main stream wait for a pending map build
 void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_imu_hint* imu, void* d_record);
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd);
 void debug_residuals(LidarDev& d, int which, const float pose[6]);

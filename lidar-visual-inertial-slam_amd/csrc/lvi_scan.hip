@@ -152,7 +152,7 @@ struct FeatArgs {
     const int *startR, *endR, *ringBase; const lvi_pt* pts;
     int *sector_idx, *sector_cnt;
     lvi_pt* corner; int* corner_idx; int* d_ncorner;
-    int* d_fresh; int* d_status;
+    int* d_fresh; int* d_status; long long* cyc;
     VoxSegDyn* ringDyn; VoxSegDyn* scanDyn; const int* ringNout;
     int N_SCAN; float edgeThreshold, surfThreshold;
 };
@@ -210,12 +210,24 @@ __global__ __launch_bounds__(256) void feat_smooth_kernel(FeatArgs a)
 // corners, smaller index first for the surf walk.
 // ---------------------------------------------------------------------------------------------
 constexpr int FEAT_THREADS = 512;
-enum : uint8_t { ST_N = 0, ST_U = 1, ST_L = 2 };
+constexpr int FEAT_EPT = FEAT_SEG_CAP / FEAT_THREADS;      // elements per thread (16)
+static_assert(FEAT_EPT == 16, "the fixed-point phase assumes 16 contiguous elements (one bitmap halfword) per thread");
+
+// bits [pos, pos+64) of a bitmap stored as 64-bit words (pos >= 0; one word of padding behind the data)
+__device__ __forceinline__ uint64_t bits_from(const uint64_t* words, int pos)
+{
+    const int wi = pos >> 6, sh = pos & 63;
+    const uint64_t lo = words[wi];
+    return sh ? ((lo >> sh) | (words[wi + 1] << (64 - sh))) : lo;
+}
 
 __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
 {
-    __shared__ float s_curv[FEAT_SEG_CAP + 16];
-    __shared__ uint8_t s_pick[FEAT_SEG_CAP + 16], s_brk[FEAT_SEG_CAP + 16], s_state[FEAT_SEG_CAP + 16];
+    __shared__ float s_curv[FEAT_SEG_CAP + 32];
+    __shared__ uint8_t s_pick[FEAT_SEG_CAP + 16], s_reach[FEAT_SEG_CAP + 16];
+    __shared__ int8_t s_label[FEAT_SEG_CAP + 16];
+    __shared__ uint64_t s_brk[FEAT_SEG_CAP / 64 + 2];         // bit j: column jump (or cloud edge) between j-1 and j
+    __shared__ unsigned short s_U[FEAT_THREADS + 4], s_L[FEAT_THREADS + 4];   // undecided / labelled bitmaps, one halfword per thread chunk (+1 pad in front)
     __shared__ unsigned long long s_key[FEAT_SEG_CAP];        // corner candidates: (curvature bits << 32) | local index
     __shared__ unsigned short s_sorted[FEAT_SEG_CAP];         // candidates by descending key
     __shared__ int s_ws[FEAT_THREADS / 64 + 2];
@@ -226,7 +238,14 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
     const int tid = threadIdx.x;
     const int fresh = *a.d_fresh;
     volatile uint8_t* v_pick = s_pick;
-    volatile uint8_t* v_state = s_state;
+    const bool stamp = (ring == 0 && tid == 0);
+    long long t_prev = stamp ? clock64() : 0, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
+
+    if (tid < 4) { s_U[tid == 0 ? 0 : FEAT_THREADS + tid] = 0; s_L[tid == 0 ? 0 : FEAT_THREADS + tid] = 0; }
+    if (tid == 0) s_brk[FEAT_SEG_CAP / 64] = ~0ull, s_brk[FEAT_SEG_CAP / 64 + 1] = ~0ull;
+    for (int j = FEAT_SEG_CAP + tid; j < FEAT_SEG_CAP + 32; j += FEAT_THREADS) s_curv[j] = 0.f;
+    __syncthreads();
 
     for (int sec = 0; sec < 6; sec++) {
         const int sR = a.startR[ring], eR = a.endR[ring];
@@ -240,16 +259,41 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             if (tid == 0) { atomicOr(a.d_status, DEV_ERR_SECTOR_TOO_LARGE); a.sector_cnt[ring * 6 + sec] = 0; }
             continue;
         }
-        // ---- load sector + halo
-        for (int j = tid; j < L; j += FEAT_THREADS) {
-            const int k = k0 + j;
-            const bool in = (k >= 0 && k < n);
-            s_curv[j] = in ? a.curv[k] : 0.f;
-            s_pick[j] = in ? a.picked[k] : 1;
-            // brk[j]: column jump between k-1 and k (featureExtraction.cpp:190-191,197-198)
-            s_brk[j] = (k >= 1 && k < n) ? (uint8_t)(abs(a.col[k] - a.col[k - 1]) > 10) : 1;
+        // ---- load sector + halo: all global loads of a thread are issued before the first use; the column
+        // break flags of 64 consecutive points are one ballot
+        {
+            float cv[FEAT_EPT]; uint8_t pk[FEAT_EPT]; bool bk[FEAT_EPT];
+#pragma unroll
+            for (int i = 0; i < FEAT_EPT; i++) {
+                const int j = tid + i * FEAT_THREADS, k = k0 + j;
+                const bool in = (j < L && k >= 0 && k < n);
+                cv[i] = in ? a.curv[k] : 0.f;
+                pk[i] = in ? a.picked[k] : (uint8_t)1;
+                // column jump between k-1 and k (featureExtraction.cpp:190-191,197-198); the cloud edge counts as one
+                bk[i] = (in && k >= 1) ? (abs(a.col[k] - a.col[k - 1]) > 10) : true;
+            }
+#pragma unroll
+            for (int i = 0; i < FEAT_EPT; i++) {
+                const int j = tid + i * FEAT_THREADS;
+                s_curv[j] = cv[i]; s_pick[j] = pk[i]; s_label[j] = 0;
+                const uint64_t m = __ballot(bk[i]);
+                if (lane_id() == 0) s_brk[j >> 6] = m;
+            }
         }
         __syncthreads();
+        // reach of the +-5 neighbour marks of a point (they stop at a column break)
+#pragma unroll 4
+        for (int i = 0; i < FEAT_EPT; i++) {
+            const int j = tid + i * FEAT_THREADS;
+            const unsigned fw = (unsigned)(bits_from(s_brk, j + 1) & 31u);                 // brk[j+1..j+5]
+            const int f = fw ? (__ffs((int)fw) - 1) : 5;
+            // backward: brk[j], brk[j-1], …, brk[j-4] must be clear for 1, 2, …, 5 steps
+            const unsigned bw = (j >= 4) ? (unsigned)(bits_from(s_brk, j - 4) & 31u) : (unsigned)(((s_brk[0] << (4 - j)) | ((1u << (4 - j)) - 1u)) & 31u);
+            const int bk = bw ? (4 - (31 - __clz((int)bw))) : 5;
+            s_reach[j] = (uint8_t)(f | (bk << 4));
+        }
+        __syncthreads();
+        LVI_STAMP(0);
         // slot 4 of the whole cloud is the never-rewritten cloudSmoothness entry {0, ind 0}: it is not a
         // candidate in either walk; k = 4 can only be sp of ring 0, sector 0.
         const int jlo = (sp == 4 && ring == 0 && sec == 0) ? 6 : 5;      // first candidate local index
@@ -258,16 +302,17 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         // the top, taking a point if it is still unpicked (max 40) and marking its +-5 neighbours.
         // Here: compact the candidates (unpicked, curvature > edgeThreshold), rank-sort them in LDS, and
         // let ONE wavefront do the greedy walk, 64 candidates at a time, conflicts resolved by ballot.
-        int ncand = 0;
-        for (int c0 = jlo; c0 < jhi; c0 += FEAT_THREADS) {
-            const int j = c0 + tid;
-            const bool cand = j < jhi && s_pick[j] == 0 && s_curv[j] > a.edgeThreshold;
-            int tot;
-            const int pos = ncand + block_excl_scan<FEAT_THREADS>(cand ? 1 : 0, s_ws, &tot);
-            if (cand) s_key[pos] = ((unsigned long long)__float_as_uint(s_curv[j]) << 32) | (unsigned)j;
-            ncand += tot;
+        int ncand;
+        {
+            int mine = 0;
+            for (int j = jlo + tid; j < jhi; j += FEAT_THREADS) mine += (s_pick[j] == 0 && s_curv[j] > a.edgeThreshold) ? 1 : 0;
+            int pos = block_excl_scan<FEAT_THREADS>(mine, s_ws, &ncand);
+            for (int j = jlo + tid; j < jhi; j += FEAT_THREADS)
+                if (s_pick[j] == 0 && s_curv[j] > a.edgeThreshold)
+                    s_key[pos++] = ((unsigned long long)__float_as_uint(s_curv[j]) << 32) | (unsigned)j;
         }
         __syncthreads();
+        LVI_STAMP(1);
         for (int i = tid; i < ncand; i += FEAT_THREADS) {
             const unsigned long long mine = s_key[i];
             int rank = 0;
@@ -275,21 +320,16 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             s_sorted[rank] = (unsigned short)(mine & 0xFFFFu);
         }
         __syncthreads();
+        LVI_STAMP(2);
         if (tid < 64) {
             const int l = tid;
             int taken = 0;
             // one "take": record, label, mark +-5 unless a column break intervenes
             auto take = [&](int win) {
-                if (l == 0) { out_idx[taken] = k0 + win; a.label[k0 + win] = 1; v_pick[win] = 1; }
-                if (l >= 1 && l <= 5) {
-                    bool ok = true;
-                    for (int q = 1; q <= l; q++) ok = ok && !s_brk[win + q];
-                    if (ok) v_pick[win + l] = 1;
-                } else if (l >= 6 && l <= 10) {
-                    const int m = l - 5; bool ok = true;
-                    for (int q = 1; q <= m; q++) ok = ok && !s_brk[win - q + 1];
-                    if (ok) v_pick[win - m] = 1;
-                }
+                const int rc = s_reach[win];
+                if (l == 0) { out_idx[taken] = k0 + win; s_label[win] = 1; v_pick[win] = 1; }
+                else if (l <= 5) { if (l <= (rc & 15)) v_pick[win + l] = 1; }
+                else if (l <= 10) { if (l - 5 <= (rc >> 4)) v_pick[win - (l - 5)] = 1; }
                 taken++;
             };
             // position ep is outside the sorted range and is visited first (:171,174)
@@ -302,13 +342,17 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
                     const int first = __ffsll((long long)m) - 1;
                     const int win = __shfl(j, first, 64);
                     take(win);
-                    alive = alive && l != first && v_pick[j] == 0;
+                    // a taken point kills exactly the candidates within its reach
+                    const int rc = s_reach[win];
+                    const int dj = j - win;
+                    if (dj == 0 || (dj > 0 && dj <= (rc & 15)) || (dj < 0 && -dj <= (rc >> 4))) alive = false;
                     m = __ballot(alive);
                 }
             }
             if (l == 0) a.sector_cnt[ring * 6 + sec] = taken;
         }
         __syncthreads();
+        LVI_STAMP(3);
         // ---- first scan of a fresh node: the stale entry {0, ind 0} is the first element of the ascending
         // walk of ring 0 / sector 0; it labels ind 0 and marks picked[1..5] (only 5 is a candidate).
         if (jlo == 6 && fresh && tid == 0) {
@@ -318,59 +362,112 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         }
         __syncthreads();
         // ---- surf walk as a fixed point (ascending curvature, position ep last; a point is labelled iff no
-        // earlier-in-order reachable neighbour is labelled).  Decisions are monotone, so in-place updates are safe.
-        for (int j = tid; j < L; j += FEAT_THREADS)
-            s_state[j] = (j >= jlo && j <= jhi && s_pick[j] == 0 && s_curv[j] < a.surfThreshold) ? ST_U : ST_N;
+        // earlier-in-order reachable neighbour is labelled).  Thread t owns the 16 CONTIGUOUS points
+        // [16t, 16t+16) = one halfword of the "undecided" (U) and "labelled" (L) bitmaps.  For each point the
+        // set of reachable neighbours that come earlier in the walk is static: an 11-bit pattern over j-5..j+5
+        // kept in registers.  A round reads the three halfwords around the chunk of each bitmap, resolves the
+        // chunk with shifts and masks, and stores its own halfwords.  Decisions are monotone, so a neighbour
+        // chunk's old or new bits are equally valid.
+        const int jb = tid * FEAT_EPT;
+        unsigned short pat[FEAT_EPT];
+        unsigned myU = 0, myL = 0;
+        {
+            float cw[FEAT_EPT + 10];                                     // curvature of j = jb-5 … jb+20
+#pragma unroll
+            for (int q = 0; q < FEAT_EPT + 10; q++) { const int j = jb - 5 + q; cw[q] = (j >= 0) ? s_curv[j] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < FEAT_EPT; i++) {
+                const int j = jb + i;
+                unsigned p = 0;
+                const bool cand = (j >= jlo && j <= jhi && s_pick[j] == 0 && cw[i + 5] < a.surfThreshold);
+                if (cand) {
+                    const float cj = cw[i + 5];
+                    const int rc = s_reach[j];
+                    const int f = rc & 15, bk = rc >> 4;
+#pragma unroll
+                    for (int q = 1; q <= 5; q++) {
+                        if (q <= f && j + q <= jhi) {
+                            const bool earlier = (j + q == jhi) ? false : (cw[i + 5 + q] < cj);      // ties go to the smaller index (j)
+                            if (earlier) p |= 1u << (5 + q);
+                        }
+                        if (q <= bk && j - q >= jlo) {
+                            const bool earlier = (j == jhi) ? true : (cw[i + 5 - q] <= cj);          // ties go to j-q
+                            if (earlier) p |= 1u << (5 - q);
+                        }
+                    }
+                    myU |= 1u << i;
+                }
+                pat[i] = (unsigned short)p;
+            }
+            s_U[tid + 1] = (unsigned short)myU; s_L[tid + 1] = 0;
+        }
         __syncthreads();
+        LVI_STAMP(4);
+        int rounds = 0;
         for (int it = 0; it < FEAT_SEG_CAP; it++) {
             if (tid == 0) s_any = 0;
             __syncthreads();
-            bool mine = false;
-            for (int j = jlo + tid; j <= jhi; j += FEAT_THREADS) {
-                if (v_state[j] != ST_U) continue;
-                const float cj = s_curv[j];
-                bool blocked = false, wait = false;
-                for (int dir = 0; dir < 2; dir++) {
-                    for (int q = 1; q <= 5; q++) {
-                        const int x = dir ? j + q : j - q;
-                        if (dir ? s_brk[j + q] : s_brk[j - q + 1]) break;
-                        if (x < jlo || x > jhi) continue;
-                        const uint8_t sx = v_state[x];
-                        if (sx == ST_N) continue;
-                        const float cx = s_curv[x];
-                        const bool earlier = (x == jhi) ? false : (j == jhi) ? true : (cx < cj || (cx == cj && x < j));
-                        if (!earlier) continue;
-                        if (sx == ST_L) blocked = true; else wait = true;
+            if (myU) {
+                // 48-bit windows: bit 16 + i <-> point jb + i
+                uint64_t Uw = (uint64_t)s_U[tid] | ((uint64_t)myU << 16) | ((uint64_t)s_U[tid + 2] << 32);
+                uint64_t Lw = (uint64_t)s_L[tid] | ((uint64_t)myL << 16) | ((uint64_t)s_L[tid + 2] << 32);
+#pragma unroll
+                for (int i = 0; i < FEAT_EPT; i++) {
+                    if (!(myU & (1u << i))) continue;
+                    const unsigned p = pat[i];
+                    const bool blocked = ((unsigned)(Lw >> (11 + i)) & p) != 0;
+                    const bool wait = ((unsigned)(Uw >> (11 + i)) & p) != 0;
+                    if (blocked || !wait) {
+                        myU &= ~(1u << i); Uw &= ~(1ull << (16 + i));
+                        if (!blocked) { myL |= 1u << i; Lw |= 1ull << (16 + i); }
                     }
                 }
-                if (blocked) v_state[j] = ST_N;
-                else if (!wait) v_state[j] = ST_L;
-                else mine = true;
+                s_U[tid + 1] = (unsigned short)myU; s_L[tid + 1] = (unsigned short)myL;
+                if (myU) s_any = 1;
             }
-            if (mine) s_any = 1;
             __syncthreads();
             const int any = s_any;
+            rounds++;
             __syncthreads();
             if (!any) break;
         }
-        // ---- apply labels and their +-5 marks, write back
-        for (int j = jlo + tid; j <= jhi; j += FEAT_THREADS) {
-            if (s_state[j] != ST_L) continue;
-            a.label[k0 + j] = -1;
-            v_pick[j] = 1;
-            for (int q = 1; q <= 5; q++) { if (s_brk[j + q]) break; v_pick[j + q] = 1; }
-            for (int q = 1; q <= 5; q++) { if (s_brk[j - q + 1]) break; v_pick[j - q] = 1; }
+        if (stamp) cyc[6] += rounds;
+        LVI_STAMP(5);
+        // ---- apply labels and their +-5 marks
+        {
+            unsigned rem = myL;
+            while (rem) {
+                const int i = __ffs((int)rem) - 1;
+                rem &= rem - 1;
+                const int j = jb + i;
+                s_label[j] = -1;
+                const int rc = s_reach[j];
+                v_pick[j] = 1;
+                for (int q = 1; q <= (rc & 15); q++) v_pick[j + q] = 1;
+                for (int q = 1; q <= (rc >> 4); q++) v_pick[j - q] = 1;
+            }
         }
         __syncthreads();
-        for (int j = tid; j < L; j += FEAT_THREADS) {
+        // ---- write back: picked incl. the 5-point spill into the neighbouring sectors, labels, surf candidates
+#pragma unroll 4
+        for (int i = 0; i < FEAT_EPT; i++) {
+            const int j = tid + i * FEAT_THREADS;
+            if (j >= L) break;
             const int k = k0 + j;
             if (k < 0 || k >= n) continue;
             a.picked[k] = s_pick[j];
-            if (j >= 5 && j <= jhi) a.surfmask[k] = (a.label[k] <= 0) ? 1 : 0;       // :231-236 (label[k] <= 0)
+            if (j >= 5 && j <= jhi) {
+                const int8_t lb = s_label[j];
+                a.label[k] = lb;
+                a.surfmask[k] = (lb <= 0) ? 1 : 0;                       // :231-236 (cloudLabel[k] <= 0)
+            }
         }
         __threadfence_block();
         __syncthreads();
+        LVI_STAMP(7);
     }
+    if (stamp) for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q];
+#undef LVI_STAMP
     if (ring == 0 && tid == 0 && n > 16) *a.d_fresh = 0;
 }
 
@@ -419,13 +516,14 @@ void layout(AR& ar, LidarDev& d)
     d.corner = ar.template alloc<lvi_pt>(d.ext_cap); d.corner_idx = ar.template alloc<int>((size_t)NS * 6 * CORNERS_PER_SECTOR);
     d.d_ncorner = ar.template alloc<int>(1);
     d.surf = ar.template alloc<lvi_pt>(d.ext_cap);
-    d.d_fresh = ar.template alloc<int>(1); d.d_status = ar.template alloc<int>(1);
+    d.d_fresh = ar.template alloc<int>(1); d.d_status = ar.template alloc<int>(1); d.d_feat_cycles = ar.template alloc<long long>(8);
     d.voxRing.allocate(ar, NS, d.ring_cap, true);
     d.cornerDS = ar.template alloc<lvi_pt>(d.ext_cap); d.surfDS = ar.template alloc<lvi_pt>(d.ext_cap);
     d.voxScan.allocate(ar, 2, d.ext_cap, false);
     d.mapCornerRaw = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfRaw = ar.template alloc<lvi_pt>(d.map_cap);
     d.mapCornerDS = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfDS = ar.template alloc<lvi_pt>(d.map_cap);
     d.voxMap.allocate(ar, 2, d.map_cap, false);
+    d.voxMap.centroid_lanes = 32;
     for (int w = 0; w < 2; w++) {
         d.grid[w].cell_start = ar.template alloc<int>((size_t)d.max_cells + 2);
         d.grid[w].sorted = ar.template alloc<lvi_pt>(d.map_cap);
@@ -450,7 +548,7 @@ FeatArgs feat_args(LidarDev& d)
     a.startR = d.startR; a.endR = d.endR; a.ringBase = d.ringBase; a.pts = d.pts;
     a.sector_idx = d.sector_idx; a.sector_cnt = d.sector_cnt;
     a.corner = d.corner; a.corner_idx = d.corner_idx; a.d_ncorner = d.d_ncorner;
-    a.d_fresh = d.d_fresh; a.d_status = d.d_status;
+    a.d_fresh = d.d_fresh; a.d_status = d.d_status; a.cyc = d.d_feat_cycles;
     a.ringDyn = d.voxRing.d_dyn; a.scanDyn = d.voxScan.d_dyn; a.ringNout = d.voxRing.d_nout;
     a.N_SCAN = d.P.N_SCAN; a.edgeThreshold = d.P.edgeThreshold; a.surfThreshold = d.P.surfThreshold;
     return a;

@@ -42,12 +42,22 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + a.dyn[s].in_off : nullptr;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     int cnt = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (mask && !mask[i]) continue;
-        const lvi_pt p = in[i];
-        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-        cnt++;
+    const int stride = gridDim.x * 256;
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        lvi_pt p[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {               // four independent loads in flight per lane
+            const int i = i0 + u * stride;
+            ok[u] = i < n && (!mask || mask[i]);
+            if (ok[u]) p[u] = in[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!ok[u]) continue;
+            mn[0] = fminf(mn[0], p[u].x); mn[1] = fminf(mn[1], p[u].y); mn[2] = fminf(mn[2], p[u].z);
+            mx[0] = fmaxf(mx[0], p[u].x); mx[1] = fmaxf(mx[1], p[u].y); mx[2] = fmaxf(mx[2], p[u].z);
+            cnt++;
+        }
     }
     // workgroup reduction, then ONE set of atomics per workgroup (a wave-level version spent 0.7 ms of a
     // 5M-point map build serialising ~57k atomics on seven addresses)
@@ -241,10 +251,10 @@ __global__ __launch_bounds__(256) void vox_heads_assign_kernel(VoxArgs a)
 }
 
 // pcl::CentroidPoint: f32 sums of x,y,z,intensity over the voxel's points, divided by the count.
-// VOX_CG lanes share a voxel: lane i sums points i, i+G, … of the voxel (sorted order = input order, the
+// VOX_CG (8, or 32 for the dense local map) lanes share a voxel: lane i sums points i, i+G, … of the voxel (sorted order = input order, the
 // sort is stable), then the G partial sums are combined in lane order.  For voxels of <= G points this
 // is exactly the sequential sum; for larger ones it is one more of the orders PCL's unstable sort allows.
-constexpr int VOX_CG = 8;
+template <int VOX_CG>
 __global__ __launch_bounds__(256) void vox_centroid_kernel(VoxArgs a)
 {
     const int s = blockIdx.y;
@@ -335,7 +345,10 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag,
     LVI_LAUNCH(ctx, nm[5], 0, hipLaunchKernelGGL(vox_heads_scan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
     LVI_LAUNCH(ctx, nm[6], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_assign_kernel, gh, dim3(256), 0, ctx.stream, a));
     const dim3 gc(std::max(1, std::min(div_up(p.seg_cap, 256 / 8), 8192)), p.nseg);
-    LVI_LAUNCH(ctx, nm[7], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel, gc, dim3(256), 0, ctx.stream, a));
+    if (p.centroid_lanes >= 32)
+        LVI_LAUNCH(ctx, nm[7], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<32>, gc, dim3(256), 0, ctx.stream, a));
+    else
+        LVI_LAUNCH(ctx, nm[7], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<8>, gc, dim3(256), 0, ctx.stream, a));
 }
 
 }  // namespace lvi

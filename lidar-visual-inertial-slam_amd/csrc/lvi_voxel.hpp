@@ -33,6 +33,7 @@ constexpr int VOX_HT = 1024;     // keys per workgroup in the head (segment boun
 struct VoxelPlan {
     int nseg = 0, seg_cap = 0, nblk_h = 0;
     bool concat_out = false;     // outputs of the segments are concatenated in out[0]'s array
+    int centroid_lanes = 8;      // lanes that share one output voxel (32 for plans with tens of points per voxel)
     SortPlan sort;
     VoxSegStatic* d_static = nullptr;
     VoxSegDyn* d_dyn = nullptr;

@@ -177,8 +177,9 @@ def test_map_build_and_knn_exact(pkg, pair, scene):
     co, cg = o.counts(), g.counts()
     assert co["map_corner_ds"] == cg["map_corner_ds"] and co["map_surf_ds"] == cg["map_surf_ds"]
     (mco, mso), (mcg, msg) = o.get_map_ds(), g.get_map_ds()
-    np.testing.assert_allclose(xyzi(mco), xyzi(mcg), rtol=0, atol=5e-5)
-    np.testing.assert_allclose(xyzi(mso), xyzi(msg), rtol=0, atol=5e-5)
+    # centroid sum order differs (PCL: unspecified; here 32 lanes per map voxel): count * 2^-23 * max|coord|
+    np.testing.assert_allclose(xyzi(mco), xyzi(mcg), rtol=0, atol=3e-4)
+    np.testing.assert_allclose(xyzi(mso), xyzi(msg), rtol=0, atol=3e-4)
     # queries: map points jittered (dense neighbourhoods) + far-away points (rejected)
     rng = np.random.default_rng(3)
     for which, m in ((0, mcg), (1, msg)):
