@@ -105,7 +105,6 @@ def main():
         d_scans.append(torch.from_numpy(sc.view(np.uint8).reshape(-1, 20).copy()).to(dev))
     total = args.warmup + args.steps + args.profile_steps
     d_rec = torch.zeros((total, 8), dtype=torch.float32, device=dev)
-    d_gather = torch.zeros((world, 8), dtype=torch.float32, device=dev) if world > 1 else None
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
@@ -120,7 +119,7 @@ def main():
         g.scan_match_async(guesses[k], d_rec[i].data_ptr())
         g.sync()
         if world > 1:
-            dist.all_gather_into_tensor(d_gather, d_rec[i:i + 1])     # RCCL: 32 B pose record per rank
+            pkg.replay.gather_records(d_rec[i:i + 1], world, dist)      # RCCL all_gather: 32 B pose record per rank
 
     def fence():
         torch.cuda.synchronize()

@@ -227,7 +227,6 @@ inline void colpiv_qr_solve_5x3(const float Ain[5][3], const float bin[5], float
     float A[5][3], b[5];
     for (int i = 0; i < rows; i++) { for (int j = 0; j < cols; j++) A[i][j] = Ain[i][j]; b[i] = bin[i]; }
     int perm[3] = {0, 1, 2};
-    float hcoef[3];
     int nonzero_pivots = cols;
     float maxpivot = 0.f;
     float max_norm0 = 0.f;
@@ -259,7 +258,6 @@ inline void colpiv_qr_solve_5x3(const float Ain[5][3], const float bin[5], float
             tau = (beta - c0) / beta;
         }
         A[k][k] = beta;
-        hcoef[k] = tau;
         if (std::abs(beta) > maxpivot) maxpivot = std::abs(beta);
         // apply H = I - tau v v^T (v = [1; essential]) to the trailing columns and to b
         // (Eigen applyHouseholderOnTheLeft: tmp = essential^T * bottom; tmp += row0)

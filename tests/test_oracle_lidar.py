@@ -1,0 +1,280 @@
+"""CPU tier: known-answer and property tests of the lidar oracle (SURVEY §8 a-0 … a-10).
+Ground truth here is hand-computed or derived independently in numpy from the reference source
+lines quoted in each test — not from the oracle itself."""
+import numpy as np
+import pytest
+
+from helpers import make_small_scene, small_params, xyzi
+
+
+@pytest.fixture()
+def L(pkg, oracle):
+    h = pkg.LidarHotpath(oracle, **small_params())
+    yield h
+    h.close()
+
+
+def _livox(pkg, xyz, line, refl=None):
+    p = np.zeros(len(xyz), pkg._abi.LIVOX_DTYPE)
+    p["x"], p["y"], p["z"] = np.asarray(xyz, np.float32).T
+    p["line"] = line
+    p["reflectivity"] = 7 if refl is None else refl
+    return p
+
+
+# ----------------------------------------------------------------------------- a-0
+def test_organize_hand_case(pkg, L):
+    # 9 message points; the LAST one is dropped (imageProjection.cpp:249); one too near, one too far, one bad line
+    xyz = [[5, 0, 0], [0, 6, 0], [0.2, 0, 0], [0, 0, 7], [200, 0, 0], [3, 4, 0], [1, 1, 1], [8, 0, 0], [9, 9, 9]]
+    line = [1, 0, 0, 1, 2, 0, 7, 3, 0]
+    info = L.organize_scan(_livox(pkg, xyz, line, refl=np.arange(9)))
+    # survivors in message order: i0(r1) i1(r0) i3(r1) i5(r0) i7(r3); ring-major, stable inside a ring
+    assert info["n"] == 5
+    np.testing.assert_array_equal(xyzi(info["cloud_deskewed"])[:, :3], [[0, 6, 0], [3, 4, 0], [5, 0, 0], [0, 0, 7], [8, 0, 0]])
+    np.testing.assert_array_equal(xyzi(info["cloud_deskewed"])[:, 3], [1, 5, 0, 3, 7])          # intensity = reflectivity
+    np.testing.assert_array_equal(info["point_range"], [6, 5, 5, 7, 8])
+    np.testing.assert_array_equal(info["point_col_ind"], [0, 1, 0, 1, 0])                        # dense per-ring counter
+    # start = count-1+5, end = count-1-5 (imageProjection.cpp:630,645)
+    np.testing.assert_array_equal(info["start_ring_index"], [4, 6, 8, 8])
+    np.testing.assert_array_equal(info["end_ring_index"], [-4, -2, -2, -1])
+
+
+def test_organize_range_gate_is_inclusive(pkg, L):
+    # range < min || range > max is rejected: exactly 1.0 and exactly 100.0 survive
+    info = L.organize_scan(_livox(pkg, [[1, 0, 0], [100, 0, 0], [0.99999, 0, 0], [100.001, 0, 0], [0, 0, 0]], [0] * 5))
+    assert info["n"] == 2
+
+
+def test_organize_horizon_truncation(pkg, oracle):
+    h = pkg.LidarHotpath(oracle, N_SCAN=2, Horizon_SCAN=3, max_raw_points=64, max_map_points=64)
+    xyz = [[2 + i, 0, 0] for i in range(10)] + [[0, 0, 0]]
+    info = h.organize_scan(_livox(pkg, xyz, [0] * 5 + [1] * 5 + [0]))
+    assert info["n"] == 6                                                       # 3 columns per ring
+    np.testing.assert_array_equal(info["point_range"], [2, 3, 4, 7, 8, 9])
+    h.close()
+
+
+# ----------------------------------------------------------------------------- a-1, a-2
+def test_smoothness_and_occlusion_against_numpy(pkg, L):
+    A = pkg._abi
+    S = pkg.synth
+    scan = S.make_scan(12001, S.loop_pose(0.9), 3)
+    L.scan_upload(scan); L.scan_organize(); L.scan_extract()
+    info = L.get_scan_info()
+    r = info["point_range"]; col = info["point_col_ind"]; n = info["n"]
+    curv = L.debug_get(A.DBG_CURVATURE, np.float32)
+    i = np.arange(5, n - 5)
+    d = (((r[i - 2] + r[i - 1]) - r[i] * np.float32(4)) + r[i + 1]) + r[i + 2]                # featureExtraction.cpp:99-101, f32 left to right
+    np.testing.assert_array_equal(curv[5:n - 5], d * d)
+    # featureExtraction.cpp:113-148, written as the scatter it is
+    pk = np.zeros(n, np.int32)
+    for k in range(5, n - 6):
+        if abs(int(col[k + 1]) - int(col[k])) < 10:
+            if float(r[k] - r[k + 1]) > 0.3:
+                pk[k - 1] = pk[k] = 1
+            elif float(r[k + 1] - r[k]) > 0.3:
+                pk[k + 1] = pk[k + 2] = 1
+        if abs(r[k - 1] - r[k]) > 0.1 * float(r[k]) and abs(r[k + 1] - r[k]) > 0.1 * float(r[k]):
+            pk[k] = 1
+    got = L.debug_get(A.DBG_PICKED_OCCL, np.int32)
+    np.testing.assert_array_equal(got[5:n - 5], pk[5:n - 5])
+
+
+# ----------------------------------------------------------------------------- a-3
+def test_extract_features_invariants(pkg, L):
+    A = pkg._abi
+    S = pkg.synth
+    scan = S.make_scan(20001, S.loop_pose(0.37, 0.01, -0.02), 12345)
+    L.scan_upload(scan); L.scan_organize(); L.scan_extract()
+    info = L.get_scan_info()
+    n = info["n"]
+    curv = L.debug_get(A.DBG_CURVATURE, np.float32)
+    occl = L.debug_get(A.DBG_PICKED_OCCL, np.int32)
+    label = L.debug_get(A.DBG_LABEL, np.int32)
+    cidx = L.debug_get(A.DBG_CORNER_INDEX, np.int32)
+    corner, surf = L.get_features()
+    assert len(cidx) == len(corner) > 50
+    np.testing.assert_array_equal(xyzi(corner), xyzi(info["cloud_deskewed"][cidx]))
+    assert (curv[cidx] > 1.0).all() and (occl[cidx] == 0).all()                                 # :177
+    assert (label[cidx] == 1).all() and (label == 1).sum() == len(cidx)
+    # per sector: at most 40, descending curvature except that position ep is visited first (:171-185)
+    pos = 0
+    for ring in range(4):
+        s, e = int(info["start_ring_index"][ring]), int(info["end_ring_index"][ring])
+        for j in range(6):
+            sp = (s * (6 - j) + e * j) // 6
+            ep = (s * (5 - j) + e * (j + 1)) // 6 - 1
+            mine = [k for k in cidx[pos:] if sp <= k <= ep]
+            take = []
+            for k in cidx[pos:]:
+                if sp <= k <= ep:
+                    take.append(k)
+                else:
+                    break
+            pos += len(take)
+            assert len(take) <= 40 and take == mine[:len(take)]
+            body = [k for k in take if k != ep]
+            assert all(curv[a] >= curv[b] for a, b in zip(body, body[1:]))
+            # neighbour suppression: two corners of one sector are more than 5 apart
+            t = np.sort(np.array(take))
+            assert len(t) < 2 or np.diff(t).min() > 5
+    assert pos == len(cidx)
+    # surf candidates = every non-corner point inside a sector, then a 0.4 m voxel grid per ring (:231-243)
+    assert 0 < len(surf) < n
+
+
+def test_forty_corner_cap(pkg, oracle):
+    """a ring made only of isolated spikes: every sector hits the cap of 40 (featureExtraction.cpp:180)"""
+    A = pkg._abi
+    h = pkg.LidarHotpath(oracle, N_SCAN=1, Horizon_SCAN=8192, max_raw_points=16384, max_map_points=64)
+    n = 6001
+    r = np.full(n, 10.0, np.float32)
+    r[::12] = 10.2                                   # spike every 12 points: curvature (4*0.2)^2... make it larger
+    r[::12] = 10.29                                  # d = -4*0.29 -> curv 1.35 > 1.0, depth jumps stay <= 0.3 (not occluded)
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    xyz = np.stack([r * np.cos(ang), r * np.sin(ang), np.zeros(n)], 1)
+    p = _livox(pkg, xyz, [0] * n)
+    info = h.organize_scan(p)
+    c, s = h.extract_features(info)
+    assert len(c) == 6 * 40
+    h.close()
+
+
+# ----------------------------------------------------------------------------- a-4
+def test_voxel_grid_hand_case(pkg, L):
+    A = pkg._abi
+    # leaf 0.5 -> inverse 2.0; min = (-0.6, 0.1, 0) -> min_b = (-2, 0, 0)
+    pts = np.array([[-0.6, 0.1, 0.0, 1], [-0.55, 0.2, 0.1, 3], [0.6, 0.1, 0.0, 5], [0.2, 0.9, 0.3, 7], [0.3, 0.8, 0.4, 9]], np.float32)
+    out = xyzi(L.voxel_downsample(pts, 0.5))
+    keys = L.debug_get(A.DBG_VOXEL_KEYS, np.int32)
+    # ijk = floor(p*2) - min_b ; div_b = (4, 2, 1) ; idx = i + 4*j
+    np.testing.assert_array_equal(keys, [0, 0, 3, 6, 6])
+    np.testing.assert_array_equal(L.debug_get(A.DBG_VOXEL_CELLS, np.int32), [0, 3, 6])
+    np.testing.assert_array_equal(L.debug_get(A.DBG_VOXEL_COUNTS, np.int32), [2, 1, 2])
+    np.testing.assert_allclose(out, [[-0.575, 0.15, 0.05, 2], [0.6, 0.1, 0.0, 5], [0.25, 0.85, 0.35, 8]], rtol=1e-6)
+
+
+def test_voxel_grid_properties(pkg, L):
+    A = pkg._abi
+    rng = np.random.default_rng(9)
+    pts = np.zeros((20000, 4), np.float32)
+    pts[:, :3] = rng.uniform(-30, 30, (20000, 3)) * [1, 1, 0.05]
+    pts[:, 3] = rng.uniform(0, 255, 20000)
+    out = xyzi(L.voxel_downsample(pts, 0.4))
+    cells = L.debug_get(A.DBG_VOXEL_CELLS, np.int32)
+    counts = L.debug_get(A.DBG_VOXEL_COUNTS, np.int32)
+    keys = L.debug_get(A.DBG_VOXEL_KEYS, np.int32)
+    assert np.all(np.diff(cells) > 0), "output order is ascending voxel idx"
+    assert counts.sum() == len(pts) and len(out) == len(cells)
+    np.testing.assert_array_equal(np.unique(keys), cells)
+    # centroid of centroids weighted by count = centroid of the input (checksum of checksums)
+    np.testing.assert_allclose((out * counts[:, None]).sum(0) / len(pts), pts.mean(0), rtol=1e-4, atol=1e-4)
+    # every centroid lies inside its voxel: same key when re-voxelised alone
+    inv = np.float32(1.0) / np.float32(0.4)
+    mn = np.floor(pts[:, :3].min(0) * inv)
+    ijk = np.floor(out[:, :3] * inv) - mn
+    div = np.floor(pts[:, :3].max(0) * inv) - mn + 1
+    np.testing.assert_array_equal((ijk[:, 0] + ijk[:, 1] * div[0] + ijk[:, 2] * div[0] * div[1]).astype(np.int32), cells)
+    # overflow rule and empty input
+    far = np.array([[0, 0, 0, 1], [3000, 3000, 3000, 2]], np.float32)
+    np.testing.assert_array_equal(xyzi(L.voxel_downsample(far, 0.01)), far)
+    assert len(L.voxel_downsample(np.zeros((0, 4), np.float32), 0.4)) == 0
+
+
+# ----------------------------------------------------------------------------- a-5
+def test_transform_cloud_matches_float64(pkg, L):
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-20, 20, (1000, 4)).astype(np.float32)
+    pose = np.array([0.03, -0.05, 1.1, 2.0, -3.0, 0.7])
+    out = xyzi(L.transform_cloud(pts, pose))
+    R = pkg.synth.rot_zyx(*pose[:3])
+    np.testing.assert_allclose(out[:, :3], pts[:, :3].astype(np.float64) @ R.T + pose[3:], atol=2e-5)
+    np.testing.assert_array_equal(out[:, 3], pts[:, 3])
+
+
+# ----------------------------------------------------------------------------- a-6 … a-10
+def test_knn_debug_is_masked_exact_knn(pkg, L):
+    rng = np.random.default_rng(6)
+    m = np.zeros((20000, 4), np.float32)
+    m[:, :3] = rng.uniform(-15, 15, (20000, 3)) * [1, 1, 0.1]
+    L.map_set(m, m)
+    mc, ms = L.get_map_ds()
+    q = np.zeros((500, 4), np.float32)
+    q[:, :3] = rng.uniform(-16, 16, (500, 3)) * [1, 1, 0.1]
+    idx, sqd = L.debug_knn(1, q)
+    ref = xyzi(ms)[:, :3]
+    for i in range(len(q)):
+        d = ((q[i, :3][None] - ref) ** 2).sum(1)
+        order = np.argsort(d, kind="stable")[:5]
+        near = d[order] < 1.0
+        assert ((idx[i] >= 0) == near).all()
+        np.testing.assert_allclose(sqd[i][near], d[order][near], rtol=1e-5)
+        assert set(idx[i][near]) == set(order[near])
+
+
+def test_residual_closed_forms(pkg, oracle):
+    """5 collinear map points -> point-to-line residual; a flat patch -> point-to-plane residual
+    (mapOptimization.cpp:1054-1092, 1130-1163)"""
+    h = pkg.LidarHotpath(oracle, **small_params(edgeFeatureMinValidNum=0, surfFeatureMinValidNum=0))
+    # corner map: points on the vertical line x=2,y=3 ; surf map: plane z=-2 (grid 0.41: one point per 0.4 voxel).
+    # (LOAM's plane model a x + b y + c z + 1 = 0 cannot represent a plane through the origin.)
+    zs = np.arange(-2, 2.01, 0.21, dtype=np.float32)
+    line = np.stack([np.full_like(zs, 2), np.full_like(zs, 3), zs, np.zeros_like(zs)], 1)
+    g = np.arange(-3, 3.01, 0.41, dtype=np.float32)
+    gx, gy = np.meshgrid(g, g)
+    plane = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, -2, np.float32), np.zeros(gx.size, np.float32)], 1)
+    h.map_set(line, plane)
+    corner = np.array([[2.3, 3.4, 0.1, 0]], np.float32)              # 0.5 m from the line
+    surf = np.array([[0.1, 0.2, -1.7, 0]], np.float32)               # 0.3 m above the plane
+    h.scan_to_map(corner, surf, np.zeros(6, np.float32))             # fills the DS scan clouds (returns TOO_FEW… soft status)
+    cc, fc = h.debug_residuals(0, np.zeros(6, np.float32))
+    cs, fs = h.debug_residuals(1, np.zeros(6, np.float32))
+    assert fc[0] == 1 and fs[0] == 1
+    s = 1 - 0.9 * 0.5
+    np.testing.assert_allclose(xyzi(cc)[0], [s * 0.6, s * 0.8, 0.0, s * 0.5], atol=2e-4)
+    s2 = 1 - 0.9 * 0.3 / np.sqrt(np.sqrt(0.01 + 0.04 + 1.7 * 1.7))
+    got = xyzi(cs)[0]
+    np.testing.assert_allclose(np.abs(got[:3]), [0, 0, s2], atol=2e-4)
+    np.testing.assert_allclose(got[2] * got[3], s2 * s2 * 0.3, atol=2e-4)      # sign of normal and distance agree
+    h.close()
+
+
+def test_scan_to_map_recovers_injected_pose(pkg, oracle):
+    sc = make_small_scene(pkg, oracle, n_raw=20001, n_kf=12)
+    h = pkg.LidarHotpath(oracle, **small_params())
+    h.map_set(sc["map_corner"], sc["map_surf"])
+    h.scan_upload(sc["scan"]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+    r = h.scan_match(sc["guess"])
+    assert r["status"] == 0 and r["converged"] and not r["degenerate"] and 2 <= r["iters"] <= 20
+    assert np.abs(r["pose"][3:] - sc["pose"][3:]).max() < 0.03          # 2 cm range noise, 1 cm map pose noise
+    assert np.abs(r["pose"][:3] - sc["pose"][:3]).max() < 0.003
+    assert np.abs(sc["guess"][3:] - sc["pose"][3:]).max() > 0.05         # the guess really was off
+    # deterministic
+    r2 = h.scan_match(sc["guess"])
+    np.testing.assert_array_equal(r["pose"], r2["pose"])
+    # IMU roll/pitch blending with weight 0.01 (mapOptimization.cpp:1345-1367): moves 1 % of the way
+    imu = dict(imu_available=1, roll=float(r["pose"][0]) + 0.1, pitch=float(r["pose"][1]) - 0.2, yaw=0.0)
+    r3 = h.scan_match(sc["guess"], imu)
+    assert abs((r3["pose"][0] - r["pose"][0]) - 0.001) < 2e-5 and abs((r3["pose"][1] - r["pose"][1]) + 0.002) < 2e-5
+    # clamps (mapOptimization.cpp:1370-1372)
+    hc = pkg.LidarHotpath(oracle, **small_params(z_tollerance=0.5))
+    hc.map_set(sc["map_corner"], sc["map_surf"])
+    hc.scan_upload(sc["scan"]); hc.scan_organize(); hc.scan_extract(); hc.scan_downsample()
+    assert hc.scan_match(sc["guess"])["pose"][5] == pytest.approx(0.5)
+    h.close(); hc.close()
+
+
+def test_soft_outcomes_and_errors(pkg, oracle):
+    A = pkg._abi
+    h = pkg.LidarHotpath(oracle, **small_params())
+    with pytest.raises(pkg.LviError) as e:
+        h.scan_organize()
+    assert e.value.code == A.LVI_ERR_STATE
+    with pytest.raises(pkg.LviError) as e:
+        h.scan_upload(np.zeros(10 ** 6, A.LIVOX_DTYPE))
+    assert e.value.code == A.LVI_ERR_CAPACITY
+    few = np.zeros((5, 4), np.float32)
+    assert h.scan_to_map(few, few, np.zeros(6))["status"] == A.LVI_NO_MAP                      # mapOptimization.cpp:1317
+    h.map_set(np.ones((30, 4), np.float32), np.ones((30, 4), np.float32))
+    assert h.scan_to_map(few, few, np.zeros(6))["status"] == A.LVI_TOO_FEW_FEATURES            # :1320
+    h.close()

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (kernel trace / pmc passes) into the summaries kept under profiles/.
+
+    python tools/summarize_prof.py kernel <dir> <out.md>            # per-kernel time table from *_kernel_trace.csv
+    python tools/summarize_prof.py pmc <fetch_dir> <write_dir> <out.json>   # HBM bytes per launch per kernel
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel)", name)
+    base = m.group(1) if m else name.split("(")[0][-60:]
+    return base
+
+
+def find(d, pat):
+    fs = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    if not fs:
+        raise SystemExit(f"no {pat} under {d}")
+    return fs
+
+
+def kernel(d, out):
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    total = 0.0
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            k = short(r["Kernel_Name"])
+            a = agg[k]; a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+            total += dur
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    with open(out, "w") as fo:
+        fo.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
+        for k, (n, t, mn, mx) in rows:
+            fo.write(f"| {k} | {n} | {t:.1f} | {t / n:.2f} | {mn:.2f} | {mx:.2f} | {100 * t / total:.1f} |\n")
+    print(open(out).read())
+
+
+def pmc(fd, wd, out):
+    def per_kernel(d, counter):
+        agg = defaultdict(lambda: [0, 0.0])
+        for f in find(d, "*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != counter:
+                    continue
+                a = agg[short(r["Kernel_Name"])]
+                a[0] += 1; a[1] += float(r["Counter_Value"])
+        return {k: v[1] / v[0] for k, v in agg.items() if v[0]}
+    fetch = per_kernel(fd, "FETCH_SIZE")
+    write = per_kernel(wd, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of
+        # the bytes of a wide coalesced streaming read → doubled; WRITE_SIZE is exact for 16-B/lane streaming stores.
+        res[k] = dict(fetch_kib_raw=f, write_kib_raw=w, hbm_bytes_per_launch=(2.0 * f + w) * 1024.0,
+                      note="read side = 2 x FETCH_SIZE (gfx950 correction), calibrated for wide coalesced streams only")
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "kernel":
+        kernel(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
