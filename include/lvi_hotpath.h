@@ -193,12 +193,20 @@ int32_t lvi_scan_match_async(lvi_lidar *h, const float pose_init[6], void *d_rec
 int32_t lvi_scan_upload_device(lvi_lidar *h, const void *d_pts, int32_t n_raw);
 int32_t lvi_map_upload_device(lvi_lidar *h, const void *d_corner_raw, int32_t nc, const void *d_surf_raw, int32_t ns);
 
+/* [hip only] the whole per-scan path in one call, for replay harnesses: scan (device pointer, Msg.point_num
+ * points) → organise → features → scan DS → [re-voxelise + re-index the uploaded raw map, as the reference
+ * does for every scan, when rebuild_map != 0] → scan matching from pose_init (imu_available = 0) → 32-byte
+ * pose record written to d_record (device pointer).  Nothing is synchronised; the launch sequence is captured
+ * once into a hipGraph per (n_raw, map size, rebuild_map) and replayed, so a call costs one graph launch. */
+int32_t lvi_scan_replay_enqueue(lvi_lidar *h, const void *d_pts, int32_t n_raw, const float pose_init[6], void *d_record, int32_t rebuild_map);
+
 /* fetch current stage outputs (host buffers) */
 int32_t lvi_get_scan_info(lvi_lidar *h, lvi_scan_info *out);
 int32_t lvi_get_features(lvi_lidar *h, lvi_cloud *corner, lvi_cloud *surf);       /* cornerCloud, surfaceCloud */
 int32_t lvi_get_scan_ds(lvi_lidar *h, lvi_cloud *corner_ds, lvi_cloud *surf_ds);  /* laserCloud{Corner,Surf}LastDS */
 int32_t lvi_get_map_ds(lvi_lidar *h, lvi_cloud *corner_ds, lvi_cloud *surf_ds);   /* laserCloud{Corner,Surf}FromMapDS */
 int32_t lvi_get_counts(lvi_lidar *h, int32_t counts[8]);
+int32_t lvi_get_pose_record(lvi_lidar *h, lvi_pose_record *out);   /* waits for and returns the last scan match's record */
 /* counts: [0] n extracted, [1] corners, [2] surf (after per-ring DS), [3] corner DS, [4] surf DS,
  *         [5] map corner DS, [6] map surf DS, [7] reserved */
 

@@ -106,11 +106,13 @@ SIGNATURES = {
     "lvi_scan_match_async": (_i32, [_vp, _P(_f32), _vp]),
     "lvi_scan_upload_device": (_i32, [_vp, _vp, _i32]),
     "lvi_map_upload_device": (_i32, [_vp, _vp, _i32, _vp, _i32]),
+    "lvi_scan_replay_enqueue": (_i32, [_vp, _vp, _i32, _P(_f32), _vp, _i32]),
     "lvi_get_scan_info": (_i32, [_vp, _P(ScanInfo)]),
     "lvi_get_features": (_i32, [_vp, _P(Cloud), _P(Cloud)]),
     "lvi_get_scan_ds": (_i32, [_vp, _P(Cloud), _P(Cloud)]),
     "lvi_get_map_ds": (_i32, [_vp, _P(Cloud), _P(Cloud)]),
     "lvi_get_counts": (_i32, [_vp, _P(_i32)]),
+    "lvi_get_pose_record": (_i32, [_vp, _vp]),
     "lvi_debug_get": (_i32, [_vp, _i32, _vp, _i64, _P(_i64)]),
     "lvi_debug_knn": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "lvi_debug_residuals": (_i32, [_vp, _i32, _P(_f32), _vp, _vp, _i32, _P(_i32)]),

@@ -202,6 +202,7 @@ void lvi_lidar_destroy(lvi_lidar* h)
     h->d.prof.collect();
     h->d.arena.release();
     if (h->d.h_icp) (void)hipHostFree(h->d.h_icp);
+    if (h->d.graphExec) (void)hipGraphExecDestroy(h->d.graphExec);
     if (h->d.ctx.stream) (void)hipStreamDestroy(h->d.ctx.stream);
     if (h->d.ctx2.stream) (void)hipStreamDestroy(h->d.ctx2.stream);
     if (h->d.evMain) (void)hipEventDestroy(h->d.evMain);
@@ -293,7 +294,7 @@ int32_t lvi_scan_match_async(lvi_lidar* h, const float pose_init[6], void* d_rec
 {
     if (!h || !pose_init) return fail(LVI_ERR_INVALID_ARG, "null argument");
     if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
-    return guarded(h, [&]() -> int32_t { stage_scan_match_enqueue(h->d, pose_init, nullptr, d_record); h->have_icp_host = false; return LVI_OK; });
+    return guarded(h, [&]() -> int32_t { set_pose_init(h->d, pose_init); stage_scan_match_enqueue(h->d, nullptr, d_record); h->have_icp_host = false; return LVI_OK; });
 }
 
 int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi_icp_result* out)
@@ -302,7 +303,8 @@ int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi
     if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
-        stage_scan_match_enqueue(d, pose, imu, nullptr);
+        set_pose_init(d, pose);
+        stage_scan_match_enqueue(d, imu, nullptr);
         int nq[3] = {0, 0, 0};
         d2h(d, d.h_icp, d.icp, 1);
         d2h(d, nq, d.voxScan.d_nout, 3);
@@ -316,6 +318,51 @@ int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi
         for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) out->n_sel[i] = s.n_sel[i];
         for (int k = 0; k < 6; k++) { out->pose[k] = s.final_pose[k]; pose[k] = s.final_pose[k]; }
         return s.status;
+    });
+}
+
+int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, const float pose_init[6], void* d_record, int32_t rebuild_map)
+{
+    if (!h || !pose_init || (n_raw > 0 && !d_pts)) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (n_raw > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    if (rebuild_map && !h->d.have_map_raw) return fail(LVI_ERR_STATE, "no map uploaded");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        join_map(d);
+        // per-call inputs go in eagerly; the captured graph only reads fixed buffers of the handle
+        d.n_raw = n_raw > 0 ? n_raw - 1 : 0;                     // moveFromCustomMsg drops the final point
+        if (d.n_raw) LVI_HIP(hipMemcpyAsync(d.raw, d_pts, sizeof(lvi_livox_pt) * (size_t)d.n_raw, hipMemcpyDeviceToDevice, d.ctx.stream));
+        LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
+        set_pose_init(d, pose_init);
+        d.have_raw = true;
+        auto run_stages = [&]() {
+            if (rebuild_map) { stage_map_build(d); d.have_map = true; }
+            stage_organize(d); d.have_org = true;
+            stage_extract(d); d.have_feat = true;
+            stage_downsample(d); d.have_ds = true;
+            stage_scan_match_enqueue(d, nullptr, nullptr);
+        };
+        if (d.prof.on) {
+            run_stages();                                         // per-kernel HIP events need eager launches
+        } else {
+            const bool stale = !d.graphExec || d.graph_n_raw != d.n_raw || d.graph_nc != d.n_map_corner || d.graph_ns != d.n_map_surf ||
+                               d.graph_rebuild != (rebuild_map ? 1 : 0);
+            if (stale) {
+                if (d.graphExec) { (void)hipGraphExecDestroy(d.graphExec); d.graphExec = nullptr; }
+                hipGraph_t graph = nullptr;
+                LVI_HIP(hipStreamBeginCapture(d.ctx.stream, hipStreamCaptureModeThreadLocal));
+                try { run_stages(); } catch (...) { (void)hipStreamEndCapture(d.ctx.stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+                LVI_HIP(hipStreamEndCapture(d.ctx.stream, &graph));
+                LVI_HIP(hipGraphInstantiate(&d.graphExec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                d.graph_n_raw = d.n_raw; d.graph_nc = d.n_map_corner; d.graph_ns = d.n_map_surf; d.graph_rebuild = rebuild_map ? 1 : 0;
+            }
+            d.have_map = d.have_map || rebuild_map; d.have_org = d.have_feat = d.have_ds = true;
+            LVI_HIP(hipGraphLaunch(d.graphExec, d.ctx.stream));
+        }
+        if (d_record) LVI_HIP(hipMemcpyAsync(d_record, &d.icp->record, sizeof(lvi_pose_record), hipMemcpyDeviceToDevice, d.ctx.stream));
+        h->have_icp_host = false;
+        return LVI_OK;
     });
 }
 
@@ -377,6 +424,17 @@ int32_t lvi_get_counts(lvi_lidar* h, int32_t counts[8])
         const Counts c = read_counts(h->d);
         counts[0] = c.n; counts[1] = c.ncorner; counts[2] = c.nsurf; counts[3] = c.ncds; counts[4] = c.nsds; counts[5] = c.mcds; counts[6] = c.msds; counts[7] = 0;
         return LVI_OK;
+    });
+}
+
+int32_t lvi_get_pose_record(lvi_lidar* h, lvi_pose_record* out)
+{
+    if (!h || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        d2h(d, out, &d.icp->record, 1);
+        sync(d);
+        return check_dev_status(d);
     });
 }
 

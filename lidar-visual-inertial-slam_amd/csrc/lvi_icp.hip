@@ -489,10 +489,15 @@ __device__ void make_pose(IcpPose& p)
     p.trig[4] = sinf(p.T[0]); p.trig[5] = cosf(p.T[0]);
 }
 
-__global__ void icp_init_kernel(IcpArgs a, float t0, float t1, float t2, float t3, float t4, float t5, int have_map)
+__global__ void set_pose_init_kernel(float* dst, float t0, float t1, float t2, float t3, float t4, float t5)
+{
+    dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3; dst[4] = t4; dst[5] = t5;
+}
+
+__global__ void icp_init_kernel(IcpArgs a, const float* __restrict__ pose_init, int have_map)
 {
     IcpState& s = *a.st;
-    s.pose.T[0] = t0; s.pose.T[1] = t1; s.pose.T[2] = t2; s.pose.T[3] = t3; s.pose.T[4] = t4; s.pose.T[5] = t5;
+    for (int k = 0; k < 6; k++) s.pose.T[k] = pose_init[k];
     make_pose(s.pose);
     s.done = 0; s.converged = 0; s.iters = 0; s.any_lm = 0; s.status = LVI_OK;
     for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) s.n_sel[i] = 0;
@@ -807,7 +812,13 @@ void stage_map_build(LidarDev& d)
     d.map_pending = true;
 }
 
-void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_imu_hint* imu, void* d_record)
+void set_pose_init(LidarDev& d, const float p[6])
+{
+    hipLaunchKernelGGL(set_pose_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, d.d_pose_init, p[0], p[1], p[2], p[3], p[4], p[5]);
+    LVI_HIP(hipGetLastError());
+}
+
+void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record)
 {
     join_map(d);
     IcpArgs a = icp_args(d);
@@ -816,8 +827,7 @@ void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_i
     a.imu_pitch = imu ? imu->imu_pitch_init : 0.f;
     a.d_record = d_record;
     const double Q = 0.25 * d.n_raw;       // nominal query count for byte accounting only
-    LVI_LAUNCH(d.ctx, "icp_init", 0, hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a,
-                                                       pose_init[0], pose_init[1], pose_init[2], pose_init[3], pose_init[4], pose_init[5], d.have_map ? 1 : 0));
+    LVI_LAUNCH(d.ctx, "icp_init", 0, hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a, d.d_pose_init, d.have_map ? 1 : 0));
     for (int it = 0; it < a.max_iters; it++) {
         LVI_LAUNCH(d.ctx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL(icp_residual_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a));
         LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, d.ctx.stream, a, it));

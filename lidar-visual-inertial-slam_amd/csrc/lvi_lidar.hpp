@@ -85,6 +85,10 @@ struct LidarDev {
     lvi_pt* coeff = nullptr; uint8_t* flag = nullptr;      // [ext_cap] corner queries first, then surf
     int nblk_icp = 0;
     IcpState* h_icp = nullptr;                             // pinned host mirror
+    float* d_pose_init = nullptr;                          // [6] initial guess of the next scan match (device)
+    // captured launch sequence of the whole per-scan path (lvi_scan_replay_enqueue)
+    hipGraphExec_t graphExec = nullptr;
+    int graph_n_raw = -1, graph_nc = -1, graph_ns = -1, graph_rebuild = -1;
     // stage flags (host)
     bool have_raw = false, have_org = false, have_feat = false, have_ds = false, have_map_raw = false, have_map = false;
     bool gen_valid = false; int gen_n = 0;
@@ -98,7 +102,8 @@ void stage_downsample(LidarDev& d);
 // lvi_icp.hip
 void stage_map_build(LidarDev& d);
 void join_map(LidarDev& d);                                // make the main stream wait for a pending map build
-void stage_scan_match_enqueue(LidarDev& d, const float pose_init[6], const lvi_imu_hint* imu, void* d_record);
+void set_pose_init(LidarDev& d, const float pose_init[6]);  // enqueue: d_pose_init <- pose_init
+void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record);   // starts from d_pose_init
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd);
 void debug_residuals(LidarDev& d, int which, const float pose[6]);
 void transform_cloud(LidarDev& d, const lvi_pt* d_in, int n, const float pose6[6], lvi_pt* d_out);

@@ -536,6 +536,7 @@ void layout(AR& ar, LidarDev& d)
     d.voxGen.allocate(ar, 1, gen_cap, false);
     d.genKeysDbg = ar.template alloc<unsigned>(gen_cap);
     d.icp = ar.template alloc<IcpState>(1);
+    d.d_pose_init = ar.template alloc<float>(8);
     d.icpPartial = ar.template alloc<double>((size_t)d.nblk_icp * 28);
     d.coeff = ar.template alloc<lvi_pt>(d.ext_cap); d.flag = ar.template alloc<uint8_t>(d.ext_cap);
 }

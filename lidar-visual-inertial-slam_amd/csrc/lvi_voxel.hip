@@ -18,6 +18,7 @@ struct VoxArgs {
     unsigned *keysA, *valsA, *keysB, *valsB;
     int* blockHeads; int* starts; int* nout;
     int nseg, seg_cap, nblk_h, concat;
+    float* mmPartial; int nblk_mm;      // [nseg][nblk_mm][8]: min xyz, max xyz, count (as float bits), pad
 };
 
 __global__ void vox_init_kernel(VoxArgs a)
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
             cnt++;
         }
     }
-    // workgroup reduction, then ONE set of atomics per workgroup (a wave-level version spent 0.7 ms of a
-    // 5M-point map build serialising ~57k atomics on seven addresses)
+    // workgroup reduction to one partial record per workgroup; vox_setup folds the records.  (Atomics on the
+    // seven bbox words serialise: ~15 ns each, 0.1 ms for a 5M-point map with 1024 workgroups.)
     __shared__ float smn[4][3], smx[4][3];
     __shared__ int scnt[4];
     cnt = wave_sum(cnt);
@@ -74,25 +75,44 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
     __syncthreads();
     if (threadIdx.x == 0) {
         int c = 0;
-        for (int w = 0; w < 4; w++) c += scnt[w];
-        if (c > 0) {
-            VoxGrid& g = a.grid[s];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int w = 0; w < 4; w++) {
+            c += scnt[w];
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                float lo = smn[0][d], hi = smx[0][d];
-                for (int w = 1; w < 4; w++) { lo = fminf(lo, smn[w][d]); hi = fmaxf(hi, smx[w][d]); }
-                atomicMin(&g.bb[d], f2ord(lo)); atomicMax(&g.bb[3 + d], f2ord(hi));
-            }
-            atomicAdd(&g.n_valid, c);
+            for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], smn[w][d]); hi[d] = fmaxf(hi[d], smx[w][d]); }
         }
+        float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + blockIdx.x) * 8;
+        rec[0] = lo[0]; rec[1] = lo[1]; rec[2] = lo[2]; rec[3] = hi[0]; rec[4] = hi[1]; rec[5] = hi[2];
+        rec[6] = __int_as_float(c); rec[7] = 0.f;
     }
 }
 
-__global__ void vox_setup_kernel(VoxArgs a)
+__global__ __launch_bounds__(64) void vox_setup_kernel(VoxArgs a)
 {
-    const int s = threadIdx.x;
-    if (s >= a.nseg) return;
+    const int s = blockIdx.x;                     // one wavefront per segment
     VoxGrid& g = a.grid[s];
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int c = 0;
+        for (int b = threadIdx.x; b < a.nblk_mm; b += 64) {
+            const float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + b) * 8;
+            const int cb = __float_as_int(rec[6]);
+            if (cb > 0) {
+                c += cb;
+#pragma unroll
+                for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], rec[d]); hi[d] = fmaxf(hi[d], rec[3 + d]); }
+            }
+        }
+        c = wave_sum(c);
+#pragma unroll
+        for (int d = 0; d < 3; d++) { lo[d] = wave_min(lo[d]); hi[d] = wave_max(hi[d]); }
+        if (threadIdx.x != 0) return;
+        g.n_valid = c;
+        if (c > 0) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) { g.bb[d] = f2ord(lo[d]); g.bb[3 + d] = f2ord(hi[d]); }
+        }
+    }
     g.overflow = 0; g.nvox = 0; g.out_off = 0;
     if (g.n_valid == 0) { g.sentinel = 0u; g.nbits = 0; a.d_nbits[s] = 0; g.inv = 0.f; return; }
     const float leaf = a.st[s].leaf;
@@ -319,7 +339,7 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
     for (int v = 0; v < g.nvox; v++) { cells[v] = (int32_t)sk[st[v]]; counts[v] = st[v + 1] - st[v]; }
     // per-point keys: recompute into keysA (scratch is free once the outputs are written)
     VoxArgs a{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
-              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0};
+              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm};
     hipLaunchKernelGGL(vox_keys_kernel, dim3(div_up(n_in, 256), 1), dim3(256), 0, ctx.stream, a);
     LVI_HIP(hipGetLastError());
     keys.resize(n_in);
@@ -330,15 +350,15 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
 void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
 {
     VoxArgs a{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
-              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0};
+              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm};
     char nm[8][48];
     const char* base[8] = {"vox_init", "vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid"};
     for (int i = 0; i < 8; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
-    const int mm_blocks = std::max(1, std::min(div_up(p.seg_cap, 256 * 16), 1024));
+    const int mm_blocks = p.nblk_mm;
     const dim3 gp(div_up(p.seg_cap, 256), p.nseg), gh(p.nblk_h, p.nseg);
     LVI_LAUNCH(ctx, nm[0], 0, hipLaunchKernelGGL(vox_init_kernel, dim3(1), dim3(64), 0, ctx.stream, a));
     LVI_LAUNCH(ctx, nm[1], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(mm_blocks, p.nseg), dim3(256), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[2], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(1), dim3(64), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[2], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg), dim3(64), 0, ctx.stream, a));
     LVI_LAUNCH(ctx, nm[3], 24.0 * n_hint, hipLaunchKernelGGL(vox_keys_kernel, gp, dim3(256), 0, ctx.stream, a));
     radix_sort_pairs(ctx, p.sort, p.d_n, p.d_nbits, 4, tag, n_hint);
     LVI_LAUNCH(ctx, nm[4], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_count_kernel, gh, dim3(256), 0, ctx.stream, a));

@@ -42,6 +42,8 @@ struct VoxelPlan {
     int* d_blockHeads = nullptr;   // [nseg][nblk_h]
     int* d_starts = nullptr;       // [nseg][seg_cap + 1]  first sorted position of every output voxel
     int* d_nout = nullptr;         // [nseg + 1]  voxels per segment, [nseg] = total
+    float* d_mmPartial = nullptr;  // [nseg][nblk_mm][8] per-workgroup bbox partials
+    int nblk_mm = 0;
 
     template <class AR> void allocate(AR& ar, int nseg_, int seg_cap_, bool concat)
     {
@@ -55,6 +57,8 @@ struct VoxelPlan {
         d_blockHeads = ar.template alloc<int>((size_t)nseg_ * nblk_h);
         d_starts = ar.template alloc<int>((size_t)nseg_ * ((size_t)seg_cap_ + 1));
         d_nout = ar.template alloc<int>(nseg_ + 1);
+        nblk_mm = std::max(1, std::min(div_up(seg_cap_, 256 * 16), 1024));
+        d_mmPartial = ar.template alloc<float>((size_t)nseg_ * nblk_mm * 8);
     }
     void set_static(const Ctx& ctx, const VoxSegStatic* host_segs) const;     // H2D of the per-segment pointers
 };

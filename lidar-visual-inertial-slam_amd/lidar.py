@@ -136,6 +136,11 @@ class LidarHotpath:
         self.lib.check(self.lib.dll.lvi_map_upload_device(self._h, C.c_void_p(int(d_corner)), int(nc), C.c_void_p(int(d_surf)), int(ns)),
                        "lvi_map_upload_device")
 
+    def scan_replay_enqueue(self, d_scan_ptr, n_raw, pose, d_record_ptr, rebuild_map=True):
+        pose_c = (C.c_float * 6)(*[float(v) for v in pose])
+        self.lib.check(self.lib.dll.lvi_scan_replay_enqueue(self._h, C.c_void_p(int(d_scan_ptr)), int(n_raw), pose_c,
+                                                            C.c_void_p(int(d_record_ptr)), 1 if rebuild_map else 0), "lvi_scan_replay_enqueue")
+
     def scan_organize(self):
         self.lib.check(self.lib.dll.lvi_scan_organize(self._h), "lvi_scan_organize")
 
@@ -175,6 +180,11 @@ class LidarHotpath:
         c = (C.c_int32 * 8)()
         self.lib.check(self.lib.dll.lvi_get_counts(self._h, c), "lvi_get_counts")
         return dict(n=c[0], corner=c[1], surf=c[2], corner_ds=c[3], surf_ds=c[4], map_corner_ds=c[5], map_surf_ds=c[6])
+
+    def get_pose_record(self):
+        rec = np.zeros(8, np.float32)
+        self.lib.check(self.lib.dll.lvi_get_pose_record(self._h, A._ptr(rec)), "lvi_get_pose_record")
+        return dict(pose=rec[:6].copy(), status=int(rec[6:7].view(np.int32)[0]), iters=int(rec[7:8].view(np.int32)[0]))
 
     def _get_pair(self, fn, name, cap_a, cap_b):
         ca, ba = self._new_cloud(cap_a)

@@ -74,6 +74,7 @@ struct lvi_lidar {
     // ---- debug
     lvo::VoxelDebug vdbg;
     std::vector<float> jtj_trace, pose_trace;
+    lvi_pose_record last_record{};
 };
 
 namespace {
@@ -622,6 +623,8 @@ int32_t scan2MapOptimization(lvi_lidar* h, const lvi_imu_hint* imu, lvi_icp_resu
         out->status = LVI_TOO_FEW_FEATURES;
     }
     std::memcpy(out->pose, h->T, sizeof(float) * 6);
+    std::memcpy(h->last_record.pose, h->T, sizeof(float) * 6);
+    h->last_record.status = out->status; h->last_record.iters = out->iters;
     return out->status;
 }
 
@@ -783,6 +786,13 @@ int32_t lvi_get_counts(lvi_lidar* h, int32_t counts[8])
     return LVI_OK;
 }
 
+int32_t lvi_get_pose_record(lvi_lidar* h, lvi_pose_record* out)
+{
+    if (!h || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    *out = h->last_record;
+    return LVI_OK;
+}
+
 // ---- one-call forms --------------------------------------------------------
 int32_t lvi_organize_scan(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw, lvi_scan_info* out)
 {
@@ -892,6 +902,7 @@ int32_t lvi_debug_residuals(lvi_lidar* h, int32_t which, const float pose[6], lv
 // hip-only entry points: present so that the symbol set is identical, but unsupported here
 int32_t lvi_scan_match_async(lvi_lidar*, const float*, void*) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_scan_upload_device(lvi_lidar*, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
+int32_t lvi_scan_replay_enqueue(lvi_lidar*, const void*, int32_t, const float*, void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_map_upload_device(lvi_lidar*, const void*, int32_t, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_prof_enable(lvi_lidar*, int32_t) { return LVI_OK; }
 int32_t lvi_prof_reset(lvi_lidar*) { return LVI_OK; }

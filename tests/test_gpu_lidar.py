@@ -326,3 +326,36 @@ def test_full_size_scan_properties(pkg, oracle, hip):
     again = g.voxel_downsample(sds, 0.4)
     assert abs(len(again) - len(sds)) <= 0.02 * len(sds)
     o.close(); g.close()
+
+
+# ----------------------------------------------------------------------------- one-call replay (hipGraph)
+def test_replay_enqueue_matches_staged_path(pkg, oracle, hip, scene):
+    """lvi_scan_replay_enqueue (captured launch sequence, map rebuilt per scan) == the staged calls == the oracle"""
+    import ctypes as C
+    P = small_params(icp_max_iters=10, icp_disable_break=1)
+    o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P); g2 = pkg.LidarHotpath(hip, **P)
+    S = pkg.synth
+    scans = [scene["scan"], S.make_scan(20001, S.loop_pose(1.3, 0.0, 0.01), 321)]
+    guesses = [scene["guess"], S.perturbed_guess(S.loop_pose(1.3, 0.0, 0.01), 9)]
+    for h in (o, g, g2):
+        h.map_upload(scene["map_corner"], scene["map_surf"])
+    # the replay entry point wants the scan in device memory: borrow the handle g's own raw buffer through a
+    # second handle's upload → not available from Python, so stage it via hipMalloc from the HIP runtime
+    hiprt = C.CDLL("libamdhip64.so")
+    for rep in range(3):                         # first call captures, later calls replay the graph
+        for sc, gs in zip(scans, guesses):
+            o.map_build(); o.scan_upload(sc); o.scan_organize(); o.scan_extract(); o.scan_downsample()
+            ro = o.scan_match(gs)
+            g.map_build(); g.scan_upload(sc); g.scan_organize(); g.scan_extract(); g.scan_downsample()
+            rg = g.scan_match(gs)
+            dptr = C.c_void_p()
+            assert hiprt.hipMalloc(C.byref(dptr), C.c_size_t(sc.nbytes)) == 0
+            assert hiprt.hipMemcpy(dptr, sc.ctypes.data_as(C.c_void_p), C.c_size_t(sc.nbytes), 1) == 0
+            g2.scan_replay_enqueue(dptr.value, len(sc), gs, 0, rebuild_map=True)
+            rr = g2.get_pose_record()
+            hiprt.hipFree(dptr)
+            assert rr["status"] == 0 and rr["iters"] == 10
+            np.testing.assert_array_equal(rr["pose"], rg["pose"])            # same kernels, same order → bitwise
+            assert np.abs(rr["pose"] - ro["pose"]).max() < 1e-4
+            assert g2.counts() == g.counts()
+    o.close(); g.close(); g2.close()

@@ -2,6 +2,7 @@
 """Turn rocprofv3 CSV output (kernel trace / pmc passes) into the summaries kept under profiles/.
 
     python tools/summarize_prof.py kernel <dir> <out.md>            # per-kernel time table from *_kernel_trace.csv
+    python tools/summarize_prof.py steady <dir> <out.md> <nsteps>   # the same over the last nsteps bench steps only
     python tools/summarize_prof.py pmc <fetch_dir> <write_dir> <out.json>   # HBM bytes per launch per kernel
 """
 import csv
@@ -43,6 +44,34 @@ def kernel(d, out):
     print(open(out).read())
 
 
+def steady(d, out, nsteps):
+    """per-kernel table over the LAST nsteps bench steps only (a step ends with icp_finish_kernel), so that
+    set-up work (map generation, torch kernels) does not dilute the averages.  Kernels of the same name but
+    different launch geometry (ring / scan / map voxel batches) are kept apart by their grid size."""
+    rows = []
+    for f in find(d, "*kernel_trace.csv"):
+        rows += list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ends = [i for i, r in enumerate(rows) if "icp_finish_kernel" in r["Kernel_Name"]]
+    if len(ends) < nsteps + 1:
+        raise SystemExit("not enough steps in the trace")
+    seg = rows[ends[-nsteps - 1] + 1: ends[-1] + 1]
+    t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    for r in seg:
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        k = f'{short(r["Kernel_Name"])} [grid {r["Grid_Size_X"]}x{r["Grid_Size_Y"]}, wg {r["Workgroup_Size_X"]}]'
+        a = agg[k]; a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
+    total = sum(v[1] for v in agg.values())
+    with open(out, "w") as fo:
+        fo.write(f"steady state: last {nsteps} steps, wall {1e-3 * (t1 - t0) / nsteps:.1f} us/step, kernel-busy sum {total / nsteps:.1f} us/step "
+                 f"(two streams overlap)\n\n")
+        fo.write("| kernel [launch geometry] | calls/step | avg us | min us | max us | us/step | % of kernel time |\n|---|---:|---:|---:|---:|---:|---:|\n")
+        for k, (n, t, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            fo.write(f"| {k} | {n / nsteps:.1f} | {t / n:.2f} | {mn:.2f} | {mx:.2f} | {t / nsteps:.1f} | {100 * t / total:.1f} |\n")
+    print(open(out).read())
+
+
 def pmc(fd, wd, out):
     def per_kernel(d, counter):
         agg = defaultdict(lambda: [0, 0.0])
@@ -69,5 +98,7 @@ def pmc(fd, wd, out):
 if __name__ == "__main__":
     if sys.argv[1] == "kernel":
         kernel(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "steady":
+        steady(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
