@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--inflight", type=int, default=4,
                     help="independent scans in flight per GPU (BASELINE config 5: batched replay); each has its own handle, "
                          "streams and map replica; a step processes this many scans per rank")
-    ap.add_argument("--enqueue", choices=["graph", "eager", "threads"], default="threads",
+    ap.add_argument("--enqueue", choices=["graph", "eager", "threads"], default="eager",
                     help="how the per-scan launch sequence is issued: one hipGraph launch per scan, eager launches from one host "
                          "thread, or eager launches from one host thread per in-flight scan (ctypes releases the GIL)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
@@ -120,7 +120,10 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=B) if args.enqueue == "threads" and B > 1 else None
 
+    enq = [0.0]
+
     def step(i):
+        t_e = time.perf_counter()
         # B independent scans: everything is enqueued for all of them before the first sync, so the GPU
         # interleaves their (mostly latency-bound) kernels; each handle has two streams of its own
         def one(b):
@@ -142,6 +145,7 @@ def main():
         else:
             for b in range(B):
                 one(b)
+        enq[0] += time.perf_counter() - t_e
         for h in hs:
             h.sync()
         if world > 1:
@@ -156,11 +160,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    enq[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    enqueue_ms_per_scan = 1e3 * enq[0] / (args.steps * B)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -216,7 +222,7 @@ def main():
                     sharding="independent scans sharded across ranks (B in flight per rank), RCCL all_gather of pose records per step"),
         roofline=roofline,
         results_ok=ok, pose_err_vs_truth=dict(trans_m=err_t, rot_rad=err_r),
-        kernel_time_ms_per_step=round(kern_ms, 4),
+        kernel_time_ms_per_step=round(kern_ms, 4), host_enqueue_ms_per_scan=round(enqueue_ms_per_scan, 4),
         top_kernels=[dict(name=s["name"], launches_per_step=s["launches"] / max(args.profile_steps, 1), avg_us=round(s["avg_us"], 2),
                           gbs=round((s["bytes_alg"] / s["launches"]) / (s["avg_us"] * 1e-6) / 1e9, 1) if s["bytes_alg"] > 0 else None)
                      for s in stats[:12]],

@@ -27,6 +27,7 @@ LVI_ICP_MAX_ITERS = 64
 DBG_CURVATURE, DBG_PICKED_OCCL, DBG_LABEL, DBG_PICKED_FINAL, DBG_CORNER_INDEX = 1, 2, 3, 4, 5
 DBG_VOXEL_KEYS, DBG_VOXEL_CELLS, DBG_VOXEL_COUNTS, DBG_ICP_JTJ, DBG_ICP_POSE_TRACE = 6, 7, 8, 9, 10
 DBG_FEAT_CYCLES = 11
+DBG_ICP_CYCLES = 12
 TDBG_PYRAMID_L1, TDBG_PYRAMID_L2, TDBG_PYRAMID_L3, TDBG_MINEIG, TDBG_GFTT_NCAND = 1, 2, 3, 4, 5
 
 PT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4")])

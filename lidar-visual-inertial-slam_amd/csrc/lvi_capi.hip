@@ -563,6 +563,10 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
                 std::vector<int32_t> v(n); d2h(d, v.data(), d.corner_idx, (size_t)n); sync(d);
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
+            case LVI_DBG_ICP_CYCLES: {
+                std::vector<long long> v(8); d2h(d, v.data(), d.d_icp_cycles, 8); sync(d);
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
             case LVI_DBG_FEAT_CYCLES: {
                 if (!need_feat()) return fail(LVI_ERR_STATE, "stage not run");
                 std::vector<long long> v(8); d2h(d, v.data(), d.d_feat_cycles, 8); sync(d);

@@ -129,14 +129,16 @@ __device__ __forceinline__ void knn_insert(Knn5& r, float dist, int idx)
     }
 }
 
-// G consecutive lanes share one query: every lane scans a strided share of the candidate rows
+// G (=8) consecutive lanes share one query: every lane scans a strided share of the candidate rows
 // (adjacent lanes read adjacent 16-B points → coalesced), keeps a private top-5, then the G lists are
 // merged by 5 rounds of a group-wide (distance, index) minimum.  All G lanes end with the same result.
 constexpr int KNN_G = 8;
 
 __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
-                                                  float qx, float qy, float qz, int sub, Knn5& out)
+                                                  float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr)
 {
+#define LVI_KT(slot) do { if (tk) tk[slot] = clock64(); } while (0)
+    LVI_KT(0);
     Knn5 r;
 #pragma unroll
     for (int k = 0; k < 5; k++) { r.d[k] = INFINITY; r.i[k] = 0x7fffffff; }
@@ -144,25 +146,43 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         int c[3];
         cell_of(m, qx, qy, qz, c);
         const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, m.dim[0] - 1);
-        if (x0 <= x1) {
-            for (int dz = -1; dz <= 1; dz++) {
-                const int z = c[2] + dz;
-                if (z < 0 || z >= m.dim[2]) continue;
-                for (int dy = -1; dy <= 1; dy++) {
-                    const int y = c[1] + dy;
-                    if (y < 0 || y >= m.dim[1]) continue;
-                    const int row = (z * m.dim[1] + y) * m.dim[0];
-                    const int b = cell_start[row + x0], e = cell_start[row + x1 + 1];
-                    for (int j = b + sub; j < e; j += KNN_G) {
-                        const lvi_pt p = sorted[j];
-                        const float ex = sub_rn(qx, p.x), ey = sub_rn(qy, p.y), ez = sub_rn(qz, p.z);
-                        const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
-                        knn_insert(r, dist, __float_as_int(p.intensity));
-                    }
-                }
-            }
+        // memory-level parallelism is everything here (the index is L2-resident, ~300-700 cycles per dependent
+        // access): first all 18 row bounds, then the first two candidates of every row, in flight together
+        int rb[9], re[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const int z = c[2] + q / 3 - 1, y = c[1] + q % 3 - 1;
+            const bool ok = x0 <= x1 && z >= 0 && z < m.dim[2] && y >= 0 && y < m.dim[1];
+            const int row = ok ? (z * m.dim[1] + y) * m.dim[0] : 0;
+            rb[q] = ok ? cell_start[row + x0] : 0;
+            re[q] = ok ? cell_start[row + x1 + 1] : 0;
+        }
+        LVI_KT(1);
+        lvi_pt p0[9], p1[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const int j0 = rb[q] + sub, j1 = j0 + KNN_G;
+            if (j0 < re[q]) p0[q] = sorted[j0];
+            if (j1 < re[q]) p1[q] = sorted[j1];
+        }
+        LVI_KT(2);
+        auto consider = [&](const lvi_pt& p) {
+            const float ex = sub_rn(qx, p.x), ey = sub_rn(qy, p.y), ez = sub_rn(qz, p.z);
+            const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+            // Only neighbours closer than 1 m can matter: the callers reject a feature unless its 5th neighbour has
+            // sqDis < 1.0, and if five such neighbours exist they ARE the five nearest.  ~3/4 of the 27-cell
+            // candidates fall outside the unit ball and skip the insertion.
+            if (dist < 1.0f) knn_insert(r, dist, __float_as_int(p.intensity));
+        };
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const int j0 = rb[q] + sub;
+            if (j0 < re[q]) consider(p0[q]);
+            if (j0 + KNN_G < re[q]) consider(p1[q]);
+            for (int j = j0 + 2 * KNN_G; j < re[q]; j += KNN_G) consider(sorted[j]);     // rows with more than 16 points
         }
     }
+    LVI_KT(3);
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         float hd = r.d[0]; int hi = r.i[0];
@@ -331,6 +351,7 @@ struct IcpArgs {
     float rot_tol, z_tol; double imu_weight;
     int imu_available; float imu_roll, imu_pitch;
     void* d_record;
+    long long* cyc;
 };
 
 __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
@@ -418,54 +439,80 @@ __device__ __forceinline__ void lm_row(const float tr[6], const lvi_pt& ori, con
     rowB = -cf.intensity;
 }
 
-constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // queries per workgroup
+constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup (32)
+static_assert(ICP_QPB <= 64, "the residual phase runs on one wavefront");
 
+// Two phases per workgroup of 32 features:
+//   A  all 256 threads: transform + 5-NN, 8 lanes per feature; the merged neighbour lists go to LDS
+//   B  ONE wavefront, one lane per feature: line / plane fit, residual, Gauss-Newton row (6+1 values) and its
+//      27 products in f64, into LDS; then 28 threads add the 32 rows in fixed order → one partial per workgroup.
+// (Doing B inside the 8-lane groups made every wavefront execute the whole eigen/QR code for 8 active lanes;
+// 512-thread workgroups with 16 lanes per feature were measured slower: only one fits per CU at this VGPR count.)
 __global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
 {
     if (a.st->done) return;
     const int nC = a.nq[0], nS = a.nq[1];
     if (blockIdx.x * ICP_QPB >= nC + nS) return;
+    const bool stamp = (blockIdx.x == (nC + nS) / ICP_QPB / 2 && threadIdx.x == 0);     // a surf workgroup in the middle
+    long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     __shared__ float sA[12], sT[6];
     __shared__ double srow[ICP_QPB][28];
+    __shared__ Knn5 snn[ICP_QPB];
     if (threadIdx.x < 12) sA[threadIdx.x] = a.st->pose.A[threadIdx.x];
     if (threadIdx.x < 6) sT[threadIdx.x] = a.st->pose.trig[threadIdx.x];
     __syncthreads();
-    const int ql = threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
-    const int t = blockIdx.x * ICP_QPB + ql;
-    const bool active = t < nC + nS;
-    const bool isC = t < nC;
-    lvi_pt ori = {0.f, 0.f, 0.f, 0.f};
-    if (active) ori = isC ? a.q[0][t] : a.q[1][t - nC];
-    const lvi_pt sel = to_map(sA, ori);
-    const int w = (active && !isC) ? 1 : 0;
-    Knn5 r;
-    // inactive groups search nothing (query far outside any grid is still fine, but skip the work)
-    if (active) knn5_search_group(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r);
-    bool ok = false;
-    lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
-    if (active && sub == 0) {
-        ok = isC ? corner_residual(a, sel, r, cf) : surf_residual(a, ori, sel, r, cf);
-        a.flag[t] = ok ? 1 : 0;
-        a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+    {
+        const int ql = threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
+        const int t = blockIdx.x * ICP_QPB + ql;
+        const bool active = t < nC + nS;
+        const bool isC = t < nC;
+        lvi_pt ori = {0.f, 0.f, 0.f, 0.f};
+        if (active) ori = isC ? a.q[0][t] : a.q[1][t - nC];
+        const lvi_pt sel = to_map(sA, ori);
+        const int w = (active && !isC) ? 1 : 0;
+        LVI_STAMP(0);
+        Knn5 r;
+        long long tk[4] = {0, 0, 0, 0};
+        if (active) knn5_search_group(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr);
+        if (active && sub == 0) snn[ql] = r;
+        LVI_STAMP(1);
+        if (stamp) { cyc[6] = tk[1] - tk[0]; cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; }
     }
-    if (sub == 0) {
+    __syncthreads();
+    if (threadIdx.x < ICP_QPB) {
+        const int ql = threadIdx.x;
+        const int t = blockIdx.x * ICP_QPB + ql;
         double* row = srow[ql];
-        if (ok) {
-            float rA[6], rB;
-            lm_row(sT, ori, cf, rA, rB);
-            int k = 0;
+        bool ok = false;
+        if (t < nC + nS) {
+            const bool isC = t < nC;
+            const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
+            const lvi_pt sel = to_map(sA, ori);
+            const Knn5 r = snn[ql];
+            lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
+            ok = isC ? corner_residual(a, sel, r, cf) : surf_residual(a, ori, sel, r, cf);
+            a.flag[t] = ok ? 1 : 0;
+            a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                float rA[6], rB;
+                lm_row(sT, ori, cf, rA, rB);
+                int k = 0;
 #pragma unroll
-            for (int rr = 0; rr < 6; rr++)
+                for (int rr = 0; rr < 6; rr++)
 #pragma unroll
-                for (int c = rr; c < 6; c++) row[k++] = (double)rA[rr] * (double)rA[c];
+                    for (int c = rr; c < 6; c++) row[k++] = (double)rA[rr] * (double)rA[c];
 #pragma unroll
-            for (int rr = 0; rr < 6; rr++) row[21 + rr] = (double)rA[rr] * (double)rB;
-            row[27] = 1.0;
-        } else {
+                for (int rr = 0; rr < 6; rr++) row[21 + rr] = (double)rA[rr] * (double)rB;
+                row[27] = 1.0;
+            }
+        }
+        if (!ok) {
 #pragma unroll
             for (int k = 0; k < 28; k++) row[k] = 0.0;
         }
     }
+    LVI_STAMP(3);
     __syncthreads();
     if (threadIdx.x < 28) {                     // fixed summation order → bit-reproducible from run to run
         double v = 0.0;
@@ -473,6 +520,9 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
         for (int q = 0; q < ICP_QPB; q++) v += srow[q][threadIdx.x];
         a.partial[(size_t)blockIdx.x * 28 + threadIdx.x] = v;
     }
+    LVI_STAMP(4);
+    if (stamp) { cyc[5] = clock64() - t_first; for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q]; }
+#undef LVI_STAMP
 }
 
 __device__ void make_pose(IcpPose& p)
@@ -766,7 +816,7 @@ IcpArgs icp_args(LidarDev& d)
     a.q[0] = d.cornerDS; a.q[1] = d.surfDS; a.nq = d.voxScan.d_nout;
     for (int w = 0; w < 2; w++) { a.meta[w] = d.grid[w].meta; a.cell_start[w] = d.grid[w].cell_start; a.sorted[w] = d.grid[w].sorted; }
     a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
-    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial;
+    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles;
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;
@@ -838,7 +888,7 @@ void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_reco
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd)
 {
     join_map(d);
-    hipLaunchKernelGGL(knn_debug_kernel, dim3(div_up(std::max(nq, 1), 256 / 8)), dim3(256), 0, d.ctx.stream,
+    hipLaunchKernelGGL(knn_debug_kernel, dim3(div_up(std::max(nq, 1), 256 / KNN_G)), dim3(256), 0, d.ctx.stream,
                        d.grid[which].meta, d.grid[which].cell_start, d.grid[which].sorted, d_queries, nq, d_idx, d_sqd);
     LVI_HIP(hipGetLastError());
 }

@@ -9,7 +9,7 @@ constexpr int ORG_TILE = 1024;          // raw points per workgroup in the organ
 constexpr int FEAT_SEG_CAP = 8192;      // max points of one ring sector held in LDS (+ halo)
 constexpr int MAX_N_SCAN = 32;
 constexpr int CORNERS_PER_SECTOR = 40;  // featureExtraction.cpp:180
-constexpr int ICP_BLOCK = 256;
+constexpr int ICP_BLOCK = 256;          // residual workgroup: 32 features x 8 lanes
 
 // device status bits (sticky until the next upload)
 enum { DEV_ERR_SECTOR_TOO_LARGE = 1, DEV_ERR_GRID_TOO_LARGE = 2 };
@@ -64,6 +64,7 @@ struct LidarDev {
     int* d_fresh = nullptr;                                // 1 until the first extract of this handle
     int* d_status = nullptr;
     long long* d_feat_cycles = nullptr;                    // [8] phase cycle counters of ring 0 (diagnostics)
+    long long* d_icp_cycles = nullptr;                     // [8] phase cycle counters of residual workgroup 0
     VoxelPlan voxRing;                                     // N_SCAN segments, leaf odometrySurfLeafSize
     // ---- scan DS
     lvi_pt *cornerDS = nullptr, *surfDS = nullptr;

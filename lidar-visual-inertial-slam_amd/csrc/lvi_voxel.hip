@@ -87,6 +87,50 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
     }
 }
 
+// grid geometry of one segment from its bbox (g.bb, g.n_valid already set): PCL's overflow rule, min_b / div_b /
+// divb_mul, key width.  Shared by the multi-workgroup and the single-workgroup paths.
+__device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap)
+{
+    g.overflow = 0; g.nvox = 0; g.out_off = 0;
+    if (g.n_valid == 0) { g.sentinel = 0u; g.nbits = 0; g.inv = 0.f; return; }
+    const float inv = div_rn(1.0f, leaf);
+    g.inv = inv;
+    float mnp[3], mxp[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mnp[d] = ord2f(g.bb[d]); mxp[d] = ord2f(g.bb[3 + d]); }
+    // dx = static_cast<int64>((max-min)*inv) + 1 … ; dx*dy*dz > INT32_MAX.  Evaluated in double (exact for
+    // every product that can pass the test; hipcc 7.2 crashes in isel on the f32→i64 form of this kernel).
+    const double dx = trunc((double)mul_rn(sub_rn(mxp[0], mnp[0]), inv)) + 1.0;
+    const double dy = trunc((double)mul_rn(sub_rn(mxp[1], mnp[1]), inv)) + 1.0;
+    const double dz = trunc((double)mul_rn(sub_rn(mxp[2], mnp[2]), inv)) + 1.0;
+    if (!(dx * dy * dz <= 2147483647.0)) {
+        // "Leaf size is too small for the input dataset. Integer indices would overflow." → output = input.
+        // Realised as one voxel per point: key = point index (already ascending, sort is a no-op permutation).
+        g.overflow = 1;
+        g.sentinel = (unsigned)seg_cap;
+        g.nbits = 32 - __clz((unsigned)seg_cap);
+        return;
+    }
+    int maxb[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        g.min_b[d] = (int)floorf(mul_rn(mnp[d], inv));
+        maxb[d] = (int)floorf(mul_rn(mxp[d], inv));
+        g.div_b[d] = maxb[d] - g.min_b[d] + 1;
+    }
+    g.mul1 = (unsigned)g.div_b[0];
+    g.mul2 = (unsigned)g.div_b[0] * (unsigned)g.div_b[1];
+    const unsigned long long ncells = (unsigned long long)g.div_b[0] * (unsigned long long)g.div_b[1] * (unsigned long long)g.div_b[2];
+    if (ncells >= 0xFFFFFFFFull) { g.sentinel = 0xFFFFFFFFu; g.nbits = 32; }
+    else {
+        g.sentinel = (unsigned)ncells;
+        int nb = 0;
+        for (unsigned long long t = ncells; t; t >>= 1) nb++;
+        g.nbits = nb;
+    }
+}
+
+
 __global__ __launch_bounds__(64) void vox_setup_kernel(VoxArgs a)
 {
     const int s = blockIdx.x;                     // one wavefront per segment
@@ -113,46 +157,20 @@ __global__ __launch_bounds__(64) void vox_setup_kernel(VoxArgs a)
             for (int d = 0; d < 3; d++) { g.bb[d] = f2ord(lo[d]); g.bb[3 + d] = f2ord(hi[d]); }
         }
     }
-    g.overflow = 0; g.nvox = 0; g.out_off = 0;
-    if (g.n_valid == 0) { g.sentinel = 0u; g.nbits = 0; a.d_nbits[s] = 0; g.inv = 0.f; return; }
-    const float leaf = a.st[s].leaf;
-    const float inv = div_rn(1.0f, leaf);
-    g.inv = inv;
-    float mnp[3], mxp[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) { mnp[d] = ord2f(g.bb[d]); mxp[d] = ord2f(g.bb[3 + d]); }
-    // dx = static_cast<int64>((max-min)*inv) + 1 … ; dx*dy*dz > INT32_MAX.  Evaluated in double (exact for
-    // every product that can pass the test; hipcc 7.2 crashes in isel on the f32→i64 form of this kernel).
-    const double dx = trunc((double)mul_rn(sub_rn(mxp[0], mnp[0]), inv)) + 1.0;
-    const double dy = trunc((double)mul_rn(sub_rn(mxp[1], mnp[1]), inv)) + 1.0;
-    const double dz = trunc((double)mul_rn(sub_rn(mxp[2], mnp[2]), inv)) + 1.0;
-    if (!(dx * dy * dz <= 2147483647.0)) {
-        // "Leaf size is too small for the input dataset. Integer indices would overflow." → output = input.
-        // Realised as one voxel per point: key = point index (already ascending, sort is a no-op permutation).
-        g.overflow = 1;
-        g.sentinel = (unsigned)a.seg_cap;
-        g.nbits = 32 - __clz((unsigned)a.seg_cap);
-        a.d_nbits[s] = g.nbits;
-        return;
-    }
-    int maxb[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        g.min_b[d] = (int)floorf(mul_rn(mnp[d], inv));
-        maxb[d] = (int)floorf(mul_rn(mxp[d], inv));
-        g.div_b[d] = maxb[d] - g.min_b[d] + 1;
-    }
-    g.mul1 = (unsigned)g.div_b[0];
-    g.mul2 = (unsigned)g.div_b[0] * (unsigned)g.div_b[1];
-    const unsigned long long ncells = (unsigned long long)g.div_b[0] * (unsigned long long)g.div_b[1] * (unsigned long long)g.div_b[2];
-    if (ncells >= 0xFFFFFFFFull) { g.sentinel = 0xFFFFFFFFu; g.nbits = 32; }
-    else {
-        g.sentinel = (unsigned)ncells;
-        int nb = 0;
-        for (unsigned long long t = ncells; t; t >>= 1) nb++;
-        g.nbits = nb;
-    }
+    vox_setup_math(g, a.st[s].leaf, a.seg_cap);
     a.d_nbits[s] = g.nbits;
+}
+
+// PCL voxel idx of input point i of a segment: ijk = int(floor(p * inv) - float(min_b)), idx = ijk . divb_mul (i32 wrap)
+__device__ __forceinline__ unsigned vox_key_of(const VoxGrid& g, const lvi_pt* in, const uint8_t* mask, int off, int i)
+{
+    if (mask && !mask[off + i]) return g.sentinel;
+    if (g.overflow) return (unsigned)i;
+    const lvi_pt p = in[off + i];
+    const int ijk0 = (int)sub_rn(floorf(mul_rn(p.x, g.inv)), (float)g.min_b[0]);
+    const int ijk1 = (int)sub_rn(floorf(mul_rn(p.y, g.inv)), (float)g.min_b[1]);
+    const int ijk2 = (int)sub_rn(floorf(mul_rn(p.z, g.inv)), (float)g.min_b[2]);
+    return (unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2;
 }
 
 __global__ __launch_bounds__(256) void vox_keys_kernel(VoxArgs a)
@@ -162,20 +180,7 @@ __global__ __launch_bounds__(256) void vox_keys_kernel(VoxArgs a)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const VoxGrid& g = a.grid[s];
-    const int off = a.dyn[s].in_off;
-    const uint8_t* mask = a.st[s].mask;
-    unsigned key;
-    if (mask && !mask[off + i]) {
-        key = g.sentinel;
-    } else if (g.overflow) {
-        key = (unsigned)i;
-    } else {
-        const lvi_pt p = a.st[s].in[off + i];
-        const int ijk0 = (int)sub_rn(floorf(mul_rn(p.x, g.inv)), (float)g.min_b[0]);
-        const int ijk1 = (int)sub_rn(floorf(mul_rn(p.y, g.inv)), (float)g.min_b[1]);
-        const int ijk2 = (int)sub_rn(floorf(mul_rn(p.z, g.inv)), (float)g.min_b[2]);
-        key = (unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2;
-    }
+    const unsigned key = vox_key_of(g, a.st[s].in, a.st[s].mask, a.dyn[s].in_off, i);
     const size_t o = (size_t)s * a.seg_cap + i;
     a.keysA[o] = key;
     a.valsA[o] = (unsigned)i;
@@ -312,6 +317,216 @@ __global__ __launch_bounds__(256) void vox_centroid_kernel(VoxArgs a)
     }
 }
 
+// =====================================================================================================
+// Single-workgroup path for tiny plans (capacity <= VOX_SMALL_MAX points per segment).
+// The multi-workgroup pipeline above is 20 launches; with a few thousand points each of them is
+// pure launch latency.  Here ONE 1024-thread workgroup per segment does bbox → geometry → keys → radix
+// sort (only as many 8-bit passes as the key width needs, ping-pong in global scratch that stays in L2)
+// → ordered compaction of the voxel starts; a second small launch writes the centroids (it needs the
+// voxel counts of the preceding segments for the concatenated output).  Same arithmetic, same stable
+// order, therefore the same bits as the large path.
+// =====================================================================================================
+constexpr int VS_THREADS = 1024;
+constexpr int VS_NW = VS_THREADS / 64;
+constexpr int VS_ITEMS = 4;
+constexpr int VS_TILE = VS_THREADS * VS_ITEMS;
+
+__global__ __launch_bounds__(VS_THREADS) void vox_small_kernel(VoxArgs a)
+{
+    const int s = blockIdx.x, tid = threadIdx.x, w = wave_id(), l = lane_id();
+    __shared__ VoxGrid sg;
+    __shared__ float smn[VS_NW][3], smx[VS_NW][3];
+    __shared__ int scnt[VS_NW];
+    __shared__ unsigned hist[256], dbase[256];
+    __shared__ unsigned waveCnt[VS_NW][256];
+    __shared__ int ws[VS_NW + 2];
+    int n = a.dyn[s].n;
+    n = n < 0 ? 0 : (n > a.seg_cap ? a.seg_cap : n);
+    const int off = a.dyn[s].in_off;
+    const lvi_pt* __restrict__ in = a.st[s].in;
+    const uint8_t* __restrict__ mask = a.st[s].mask;
+    // ---- bbox
+    {
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int cnt = 0;
+        for (int i = tid; i < n; i += VS_THREADS) {
+            if (mask && !mask[off + i]) continue;
+            const lvi_pt p = in[off + i];
+            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+            cnt++;
+        }
+        cnt = wave_sum(cnt);
+#pragma unroll
+        for (int d = 0; d < 3; d++) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+        if (l == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) { smn[w][d] = mn[d]; smx[w][d] = mx[d]; }
+            scnt[w] = cnt;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int q = 0; q < VS_NW; q++) {
+            c += scnt[q];
+#pragma unroll
+            for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], smn[q][d]); hi[d] = fmaxf(hi[d], smx[q][d]); }
+        }
+        sg.n_valid = c;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { sg.bb[d] = c > 0 ? f2ord(lo[d]) : 0xFFFFFFFFu; sg.bb[3 + d] = c > 0 ? f2ord(hi[d]) : 0u; }
+        vox_setup_math(sg, a.st[s].leaf, a.seg_cap);
+        a.d_n[s] = n; a.d_nbits[s] = sg.nbits;
+    }
+    __syncthreads();
+    const size_t so = (size_t)s * a.seg_cap;
+    // ---- keys
+    for (int i = tid; i < n; i += VS_THREADS) { a.keysA[so + i] = vox_key_of(sg, in, mask, off, i); a.valsA[so + i] = (unsigned)i; }
+    __syncthreads();
+    // ---- LSD radix sort, ceil(nbits/8) passes
+    const int npass = (sg.nbits + 7) >> 3;
+    const uint64_t lt = lanemask_lt();
+    for (int pass = 0; pass < npass; pass++) {
+        const int shift = pass * 8;
+        const unsigned* __restrict__ srcK = ((pass & 1) ? a.keysB : a.keysA) + so;
+        const unsigned* __restrict__ srcV = ((pass & 1) ? a.valsB : a.valsA) + so;
+        unsigned* __restrict__ dstK = ((pass & 1) ? a.keysA : a.keysB) + so;
+        unsigned* __restrict__ dstV = ((pass & 1) ? a.valsA : a.valsB) + so;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += VS_THREADS) atomicAdd(&hist[(srcK[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            int tot;
+            const int ex = block_excl_scan<VS_THREADS>(tid < 256 ? (int)hist[tid] : 0, ws, &tot);
+            if (tid < 256) dbase[tid] = (unsigned)ex;                  // running global base of every digit
+        }
+        __syncthreads();
+        for (int base = 0; base < n; base += VS_TILE) {
+#pragma unroll
+            for (int q = 0; q < VS_NW; q += 4) if (tid < 256) { waveCnt[q][tid] = 0; waveCnt[q + 1][tid] = 0; waveCnt[q + 2][tid] = 0; waveCnt[q + 3][tid] = 0; }
+            __syncthreads();
+            unsigned k[VS_ITEMS], v[VS_ITEMS]; unsigned short r[VS_ITEMS];
+            const int cbase = base + w * (VS_ITEMS * 64);
+#pragma unroll
+            for (int i = 0; i < VS_ITEMS; i++) {
+                const int idx = cbase + i * 64 + l;
+                const bool valid = idx < n;
+                k[i] = valid ? srcK[idx] : 0u; v[i] = valid ? srcV[idx] : 0u;
+                const unsigned d = (k[i] >> shift) & 255u;
+                uint64_t peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t m = __ballot(bit); peers &= bit ? m : ~m; }
+                r[i] = 0;
+                if (valid) {
+                    const unsigned prior = waveCnt[w][d];
+                    r[i] = (unsigned short)(prior + __popcll(peers & lt));
+                    if ((peers & lt) == 0) waveCnt[w][d] = prior + __popcll(peers);
+                }
+            }
+            __syncthreads();
+            unsigned tileCnt = 0;
+            if (tid < 256) {                                           // per digit: offsets of the waves inside the tile
+#pragma unroll
+                for (int q = 0; q < VS_NW; q++) { const unsigned c = waveCnt[q][tid]; waveCnt[q][tid] = tileCnt; tileCnt += c; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < VS_ITEMS; i++) {
+                const int idx = cbase + i * 64 + l;
+                if (idx < n) {
+                    const unsigned d = (k[i] >> shift) & 255u;
+                    const unsigned g = dbase[d] + waveCnt[w][d] + r[i];
+                    dstK[g] = k[i]; dstV[g] = v[i];
+                }
+            }
+            __syncthreads();
+            if (tid < 256) dbase[tid] += tileCnt;
+            __syncthreads();
+        }
+    }
+    // ---- voxel starts: ordered compaction of the first entry of every distinct key
+    const unsigned* keys = ((npass & 1) ? a.keysB : a.keysA) + so;
+    int* starts = a.starts + (size_t)s * ((size_t)a.seg_cap + 1);
+    const unsigned sent = sg.sentinel;
+    int carry = 0, first_sent = n;
+    for (int base = 0; base < n; base += VS_TILE) {
+        bool h[VS_ITEMS]; int c = 0;
+#pragma unroll
+        for (int j = 0; j < VS_ITEMS; j++) { const int i = base + tid * VS_ITEMS + j; h[j] = (i < n) && is_head(keys, i, sent); c += h[j]; }
+        int tot;
+        int vv = carry + block_excl_scan<VS_THREADS>(c, ws, &tot);
+#pragma unroll
+        for (int j = 0; j < VS_ITEMS; j++) {
+            const int i = base + tid * VS_ITEMS + j;
+            if (i >= n) break;
+            if (h[j]) starts[vv++] = i;
+            if (keys[i] == sent && (i == 0 || keys[i - 1] != sent)) first_sent = i;
+        }
+        carry += tot;
+    }
+    // end of the last voxel = first masked-out entry (at most one thread found it), else n
+    __shared__ int s_end;
+    if (tid == 0) s_end = n;
+    __syncthreads();
+    if (first_sent < n) s_end = first_sent;
+    __syncthreads();
+    if (tid == 0) {
+        starts[carry] = s_end;
+        sg.nvox = carry;
+        a.grid[s] = sg;
+    }
+}
+
+// out offsets of the concatenated output + centroids, 8 lanes per voxel (as vox_centroid_kernel<8>)
+__global__ __launch_bounds__(VS_THREADS) void vox_small_finish_kernel(VoxArgs a)
+{
+    const int s = blockIdx.x;
+    __shared__ int s_off;
+    if (threadIdx.x == 0) {
+        int off = 0, total = 0;
+        for (int q = 0; q < a.nseg; q++) { if (q < s) off += a.grid[q].nvox; total += a.grid[q].nvox; }
+        s_off = a.concat ? off : 0;
+        a.grid[s].out_off = s_off;
+        a.nout[s] = a.grid[s].nvox;
+        if (s == 0) a.nout[a.nseg] = total;
+    }
+    __syncthreads();
+    const int out_off = s_off;
+    const int nvox = a.grid[s].nvox;
+    constexpr int G = 8;
+    const int sub = threadIdx.x % G;
+    const int* starts = a.starts + (size_t)s * ((size_t)a.seg_cap + 1);
+    const unsigned* vals = sorted_vals(a, s);
+    const lvi_pt* __restrict__ in = a.st[s].in + a.dyn[s].in_off;
+    lvi_pt* out = a.concat ? a.st[0].out : a.st[s].out;
+    for (int v0 = 0; v0 < nvox; v0 += VS_THREADS / G) {
+        const int v = v0 + threadIdx.x / G;
+        const bool act = v < nvox;
+        int b = 0, e = 0;
+        if (act) { b = starts[v]; e = starts[v + 1]; }
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        for (int j = b + sub; j < e; j += G) {
+            const lvi_pt p = in[vals[j]];
+            sx = add_rn(sx, p.x); sy = add_rn(sy, p.y); sz = add_rn(sz, p.z); si = add_rn(si, p.intensity);
+        }
+        float tx = sx, ty = sy, tz = sz, ti = si;
+#pragma unroll
+        for (int q = 1; q < G; q++) {
+            const float ox = __shfl_down(sx, q, G), oy = __shfl_down(sy, q, G), oz = __shfl_down(sz, q, G), oi = __shfl_down(si, q, G);
+            if (b + q < e) { tx = add_rn(tx, ox); ty = add_rn(ty, oy); tz = add_rn(tz, oz); ti = add_rn(ti, oi); }
+        }
+        if (act && sub == 0) {
+            const float cnt = (float)(e - b);
+            lvi_pt o;
+            o.x = div_rn(tx, cnt); o.y = div_rn(ty, cnt); o.z = div_rn(tz, cnt); o.intensity = div_rn(ti, cnt);
+            out[out_off + v] = o;
+        }
+    }
+}
+
 }  // namespace
 
 void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs) const
@@ -351,6 +566,13 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag,
 {
     VoxArgs a{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
               p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm};
+    if (p.seg_cap <= VOX_SMALL_MAX) {
+        char n0[48], n1[48];
+        snprintf(n0, sizeof(n0), "vox_small/%s", tag); snprintf(n1, sizeof(n1), "vox_small_finish/%s", tag);
+        LVI_LAUNCH(ctx, n0, 16.0 * n_hint, hipLaunchKernelGGL(vox_small_kernel, dim3(p.nseg), dim3(VS_THREADS), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, n1, 20.0 * n_hint, hipLaunchKernelGGL(vox_small_finish_kernel, dim3(p.nseg), dim3(VS_THREADS), 0, ctx.stream, a));
+        return;
+    }
     char nm[8][48];
     const char* base[8] = {"vox_init", "vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid"};
     for (int i = 0; i < 8; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);

@@ -28,6 +28,8 @@ struct VoxGrid {                 // device, per segment
     int out_off;
 };
 
+constexpr int VOX_SMALL_MAX = 4096;     // only tiny plans take the single-workgroup path: measured on MI355X, one CU is
+                                        // latency-bound beyond a few thousand points (33 k points: 0.5 ms vs 0.15 ms multi-workgroup)
 constexpr int VOX_HT = 1024;     // keys per workgroup in the head (segment boundary) kernels
 
 struct VoxelPlan {

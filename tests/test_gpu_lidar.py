@@ -146,6 +146,23 @@ def test_voxel_downsample_keys_bit_exact(pkg, pair):
     _voxel_case(pkg, o, g, -np.abs(c), 0.2)
 
 
+def test_voxel_single_workgroup_path(pkg, oracle, hip):
+    """capacities <= 4096 take the one-workgroup-per-segment voxel kernels: same keys, cells, counts"""
+    kw = dict(N_SCAN=4, Horizon_SCAN=1000, max_raw_points=4096, max_map_points=4096)
+    o = pkg.LidarHotpath(oracle, **kw); g = pkg.LidarHotpath(hip, **kw)
+    rng = np.random.default_rng(21)
+    for n in (1, 2, 63, 64, 65, 1023, 1024, 1025, 4096):
+        pts = np.zeros((n, 4), np.float32)
+        pts[:, :3] = rng.uniform(-25, 25, (n, 3)) * [1, 1, 0.2]
+        pts[:, 3] = rng.uniform(0, 255, n)
+        for leaf in (0.4, 0.1, 3.0):
+            _voxel_case(pkg, o, g, pts, leaf)
+    far = np.array([[0, 0, 0, 1], [3000, 3000, 3000, 2], [1, 1, 1, 3]], np.float32)
+    np.testing.assert_array_equal(xyzi(g.voxel_downsample(far, 0.01)), far)
+    assert len(g.voxel_downsample(np.zeros((0, 4), np.float32), 0.4)) == 0
+    o.close(); g.close()
+
+
 def test_voxel_downsample_edge_cases(pkg, pair):
     o, g = pair
     assert len(g.voxel_downsample(np.zeros((0, 4), np.float32), 0.4)) == 0
