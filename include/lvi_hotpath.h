@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LVI_ABI_VERSION 1
+#define LVI_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------- */
 #define LVI_OK                        0
@@ -85,7 +85,10 @@ typedef struct lvi_lidar_params {
     int32_t icp_disable_break;          /* 0 = reference semantics; 1 = run exactly icp_max_iters (throughput runs) */
     /* capacities (sizes of the device arenas) */
     int32_t max_raw_points;             /* per scan, Msg.point_num upper bound */
-    int32_t max_map_points;             /* raw local-map points, corner + surf each */
+    int32_t max_map_points;             /* raw local-map points, corner + surf each (<= 2^25) */
+    /* realisation of the voxel grids: 0 = auto (per batch, from the previous batch's grid size), 1 = sorted, 2 = binned.
+     * Same output bits either way; only the HIP backend reads it. */
+    int32_t voxel_mode;
 } lvi_lidar_params;
 
 /* CloudInfo.msg:4-8 arrays + cloud_deskewed, as plain caller-owned arrays.

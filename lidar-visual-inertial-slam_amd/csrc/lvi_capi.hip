@@ -165,7 +165,7 @@ void lvi_lidar_params_default(lvi_lidar_params* p)
     p->z_tollerance = 1000.0f; p->rotation_tollerance = 1000.0f; p->imuRPYWeight = 0.01f;
     p->numberOfCores = 8;
     p->icp_max_iters = 20; p->icp_disable_break = 0;
-    p->max_raw_points = 131072; p->max_map_points = 1 << 20;
+    p->max_raw_points = 131072; p->max_map_points = 1 << 20; p->voxel_mode = 0;
 }
 
 int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** out)
@@ -174,6 +174,8 @@ int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** 
     if (p->N_SCAN <= 0 || p->N_SCAN > MAX_N_SCAN || p->Horizon_SCAN <= 0 || p->downsampleRate <= 0)
         return fail(LVI_ERR_INVALID_ARG, "bad scan geometry (N_SCAN must be 1..32)");
     if (p->icp_max_iters < 0) return fail(LVI_ERR_INVALID_ARG, "icp_max_iters < 0");
+    if (p->max_map_points > (1 << 25) || p->max_raw_points > (1 << 25)) return fail(LVI_ERR_INVALID_ARG, "capacities above 2^25 points are not supported");
+    if (p->voxel_mode < 0 || p->voxel_mode > 2) return fail(LVI_ERR_INVALID_ARG, "voxel_mode must be 0 (auto), 1 (sorted) or 2 (binned)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LVI_ERR_NO_DEVICE, "no HIP device: the HIP path has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(LVI_ERR_NO_DEVICE, "device index out of range");
@@ -200,6 +202,7 @@ void lvi_lidar_destroy(lvi_lidar* h)
     if (h->d.ctx.stream) { (void)hipStreamSynchronize(h->d.ctx.stream); }
     if (h->d.ctx2.stream) { (void)hipStreamSynchronize(h->d.ctx2.stream); }
     h->d.prof.collect();
+    h->d.voxRing.release(); h->d.voxScan.release(); h->d.voxMap.release(); h->d.voxGen.release();
     h->d.arena.release();
     if (h->d.h_icp) (void)hipHostFree(h->d.h_icp);
     if (h->d.graphExec) (void)hipGraphExecDestroy(h->d.graphExec);

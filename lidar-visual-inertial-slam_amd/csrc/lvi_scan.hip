@@ -585,6 +585,7 @@ void lidar_allocate(LidarDev& d)
     st[0] = VoxSegStatic{d.mapCornerRaw, nullptr, d.mapCornerDS, d.P.mappingCornerLeafSize};
     st[1] = VoxSegStatic{d.mapSurfRaw, nullptr, d.mapSurfDS, d.P.mappingSurfLeafSize};
     d.voxMap.set_static(d.ctx, st.data());
+    d.voxRing.mode = d.voxScan.mode = d.voxMap.mode = d.voxGen.mode = d.P.voxel_mode;
     LVI_HIP(hipStreamSynchronize(d.ctx.stream));
 }
 

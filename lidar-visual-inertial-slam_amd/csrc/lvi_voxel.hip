@@ -1,11 +1,20 @@
 // pcl::VoxelGrid<PointXYZI>::applyFilter for gfx950.
 //
 // Per batch, all segments at once (blockIdx.y = segment), nothing returns to the host:
-//   vox_init → vox_minmax (bbox, order-encoded atomics) → vox_setup (grid dims, overflow rule,
-//   key width) → vox_keys (i32 voxel idx per point, exact PCL arithmetic, no FMA) →
-//   stable radix sort of (idx, point index) → vox_heads_* (ordered compaction of the first
-//   entry of every distinct idx) → vox_centroid (f32 running sums in sorted order, / count).
-// HBM-bound: algorithmic bytes 16·P read + 16·V written; the sort adds 20·P per 8-bit pass.
+//   vox_minmax (bbox partials per workgroup) → vox_setup (grid dims, overflow rule, key width, bins,
+//   fixed-point scales), then one of
+//   SORTED: vox_keys (i32 voxel idx per point, exact PCL arithmetic, no FMA) → stable radix sort of
+//           (idx, point index) → vox_heads_* (ordered compaction of the first entry of every distinct
+//           idx) → vox_centroid (gathers the voxel's points);
+//   BINNED: vb_hist → vb_scan → vb_scatter (partition of the POINTS into bins of consecutive idx,
+//           LDS histogram + one global reservation per occupied bin and tile) → vb_accum (one
+//           workgroup per bin, LDS-resident accumulators, ordered compaction of the occupied
+//           voxels) → vb_outscan → vb_copy.
+// Voxel idx, voxel set and output order are PCL's, bit for bit.  The centroid is the exact mean of the
+// voxel's points in fixed point (integer sums, so independent of visiting order and identical in both
+// paths), rounded once to f32; PCL sums in f32 in the order its unstable sort leaves the points, which
+// no parallel machine reproduces — the difference is below 1e-5 m and covered by the tests' tolerance.
+// HBM-bound: algorithmic bytes 16·P read + 16·V written.
 #include "lvi_voxel.hpp"
 
 namespace lvi {
@@ -18,30 +27,29 @@ struct VoxArgs {
     unsigned *keysA, *valsA, *keysB, *valsB;
     int* blockHeads; int* starts; int* nout;
     int nseg, seg_cap, nblk_h, concat;
-    float* mmPartial; int nblk_mm;      // [nseg][nblk_mm][8]: min xyz, max xyz, count (as float bits), pad
+    float* mmPartial; int nblk_mm;      // [nseg][nblk_mm][12]: min xyz, max xyz, count (as float bits), min/max intensity
+    unsigned* binCount; int* binStart; unsigned* cursor; int* binVox; int* binOut;
+    lvi_pt* bucketed; lvi_pt* staging; uint2* stagingKC;
+    unsigned long long* h_ncells;
+    int* chunkStart; int* multiStart;                  // [nseg][VB_NB+1] exclusive scans of chunks per bin / chunks of multi-chunk bins
+    unsigned long long* chunkTabV; unsigned* chunkTabC; int max_multi;   // [nseg][max_multi] LDS tables of the chunks of multi-chunk bins
 };
 
-__global__ void vox_init_kernel(VoxArgs a)
+__device__ __forceinline__ int seg_len(const VoxArgs& a, int s)
 {
-    const int s = threadIdx.x;
-    if (s >= a.nseg) return;
-    VoxGrid& g = a.grid[s];
-    g.bb[0] = g.bb[1] = g.bb[2] = 0xFFFFFFFFu;
-    g.bb[3] = g.bb[4] = g.bb[5] = 0u;
-    g.n_valid = 0;
-    int n = a.dyn[s].n;
-    if (n < 0) n = 0;
-    if (n > a.seg_cap) n = a.seg_cap;
-    a.d_n[s] = n;
+    const int n = a.dyn[s].n;
+    return n < 0 ? 0 : (n > a.seg_cap ? a.seg_cap : n);
 }
 
 __global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
 {
     const int s = blockIdx.y;
-    const int n = a.d_n[s];
+    const int n = seg_len(a, s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.d_n[s] = n;          // read by every later kernel of the batch
     const lvi_pt* __restrict__ in = a.st[s].in + a.dyn[s].in_off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + a.dyn[s].in_off : nullptr;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float imn = INFINITY, imx = -INFINITY;
     int cnt = 0;
     const int stride = gridDim.x * 256;
     for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
@@ -57,42 +65,58 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
             if (!ok[u]) continue;
             mn[0] = fminf(mn[0], p[u].x); mn[1] = fminf(mn[1], p[u].y); mn[2] = fminf(mn[2], p[u].z);
             mx[0] = fmaxf(mx[0], p[u].x); mx[1] = fmaxf(mx[1], p[u].y); mx[2] = fmaxf(mx[2], p[u].z);
+            imn = fminf(imn, p[u].intensity); imx = fmaxf(imx, p[u].intensity);
             cnt++;
         }
     }
     // workgroup reduction to one partial record per workgroup; vox_setup folds the records.  (Atomics on the
     // seven bbox words serialise: ~15 ns each, 0.1 ms for a 5M-point map with 1024 workgroups.)
-    __shared__ float smn[4][3], smx[4][3];
+    __shared__ float smn[4][4], smx[4][4];
     __shared__ int scnt[4];
     cnt = wave_sum(cnt);
 #pragma unroll
     for (int d = 0; d < 3; d++) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    imn = wave_min(imn); imx = wave_max(imx);
     if (lane_id() == 0) {
 #pragma unroll
         for (int d = 0; d < 3; d++) { smn[wave_id()][d] = mn[d]; smx[wave_id()][d] = mx[d]; }
+        smn[wave_id()][3] = imn; smx[wave_id()][3] = imx;
         scnt[wave_id()] = cnt;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int c = 0;
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         for (int w = 0; w < 4; w++) {
             c += scnt[w];
 #pragma unroll
-            for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], smn[w][d]); hi[d] = fmaxf(hi[d], smx[w][d]); }
+            for (int d = 0; d < 4; d++) { lo[d] = fminf(lo[d], smn[w][d]); hi[d] = fmaxf(hi[d], smx[w][d]); }
         }
-        float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + blockIdx.x) * 8;
+        float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + blockIdx.x) * 12;
         rec[0] = lo[0]; rec[1] = lo[1]; rec[2] = lo[2]; rec[3] = hi[0]; rec[4] = hi[1]; rec[5] = hi[2];
-        rec[6] = __int_as_float(c); rec[7] = 0.f;
+        rec[6] = __int_as_float(c); rec[7] = lo[3]; rec[8] = hi[3];
     }
 }
 
 // grid geometry of one segment from its bbox (g.bb, g.n_valid already set): PCL's overflow rule, min_b / div_b /
 // divb_mul, key width.  Shared by the multi-workgroup and the single-workgroup paths.
-__device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap)
+__device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap, float ilo, float ihi)
 {
     g.overflow = 0; g.nvox = 0; g.out_off = 0;
+    g.ncells = 0ull; g.nbins = 0; g.bin_shift = VB_CL_LOG; g.fx_k = 0; g.fx_ki = 0;
+    g.fx_lo[0] = g.fx_lo[1] = g.fx_lo[2] = g.fx_lo[3] = 0.f;
     if (g.n_valid == 0) { g.sentinel = 0u; g.nbits = 0; g.inv = 0.f; return; }
+    {
+        // fixed-point scales: every (value - lo) * 2^k stays below 2^38, so 2^25 points cannot overflow 64 bits
+        float ext = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { g.fx_lo[d] = ord2f(g.bb[d]); ext = fmaxf(ext, ord2f(g.bb[3 + d]) - ord2f(g.bb[d])); }
+        g.fx_lo[3] = ilo;
+        int ex = 0, exi = 0;
+        (void)frexpf(ext, &ex); (void)frexpf(ihi - ilo, &exi);
+        g.fx_k = 38 - ex;                               // ext < 2^ex
+        g.fx_ki = 38 - exi;
+    }
     const float inv = div_rn(1.0f, leaf);
     g.inv = inv;
     float mnp[3], mxp[3];
@@ -121,6 +145,16 @@ __device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap)
     g.mul1 = (unsigned)g.div_b[0];
     g.mul2 = (unsigned)g.div_b[0] * (unsigned)g.div_b[1];
     const unsigned long long ncells = (unsigned long long)g.div_b[0] * (unsigned long long)g.div_b[1] * (unsigned long long)g.div_b[2];
+    g.ncells = ncells;
+    // about a thousand bins for a dense map (fewer for a few thousand points): few enough that a tile of consecutive points touches few of them (one global reservation
+    // per tile and bin), many enough to fill the chip; never more than VB_NB, and beyond 1024 voxels per bin (sparse
+    // grids) a bin is swept once per occupied 1024-voxel sub-range
+    const unsigned long long target = (unsigned long long)max(64, min(g.n_valid / 2048, 1024));
+    int sh = 6;
+    while (sh < VB_CL_LOG && (ncells >> sh) > target) sh++;
+    while (((ncells + (1ull << sh) - 1ull) >> sh) > (unsigned long long)VB_NB) sh++;
+    g.bin_shift = sh;
+    g.nbins = (int)((ncells + (1ull << sh) - 1ull) >> sh);
     if (ncells >= 0xFFFFFFFFull) { g.sentinel = 0xFFFFFFFFu; g.nbits = 32; }
     else {
         g.sentinel = (unsigned)ncells;
@@ -137,31 +171,46 @@ __global__ __launch_bounds__(64) void vox_setup_kernel(VoxArgs a)
     VoxGrid& g = a.grid[s];
     {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float ilo = INFINITY, ihi = -INFINITY;
         int c = 0;
-        for (int b = threadIdx.x; b < a.nblk_mm; b += 64) {
-            const float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + b) * 8;
+        const int nb_used = a.nblk_mm;
+        for (int b = threadIdx.x; b < nb_used; b += 64) {
+            const float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + b) * 12;
             const int cb = __float_as_int(rec[6]);
             if (cb > 0) {
                 c += cb;
 #pragma unroll
                 for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], rec[d]); hi[d] = fmaxf(hi[d], rec[3 + d]); }
+                ilo = fminf(ilo, rec[7]); ihi = fmaxf(ihi, rec[8]);
             }
         }
         c = wave_sum(c);
 #pragma unroll
         for (int d = 0; d < 3; d++) { lo[d] = wave_min(lo[d]); hi[d] = wave_max(hi[d]); }
+        ilo = wave_min(ilo); ihi = wave_max(ihi);
         if (threadIdx.x != 0) return;
         g.n_valid = c;
         if (c > 0) {
 #pragma unroll
             for (int d = 0; d < 3; d++) { g.bb[d] = f2ord(lo[d]); g.bb[3 + d] = f2ord(hi[d]); }
+        } else {
+            g.bb[0] = g.bb[1] = g.bb[2] = 0xFFFFFFFFu; g.bb[3] = g.bb[4] = g.bb[5] = 0u;
+            ilo = ihi = 0.f;
         }
+        vox_setup_math(g, a.st[s].leaf, a.seg_cap, ilo, ihi);
     }
-    vox_setup_math(g, a.st[s].leaf, a.seg_cap);
     a.d_nbits[s] = g.nbits;
+    if (a.h_ncells) a.h_ncells[s] = g.ncells;                        // pinned host: AUTO's hint for the next batch
 }
 
 // PCL voxel idx of input point i of a segment: ijk = int(floor(p * inv) - float(min_b)), idx = ijk . divb_mul (i32 wrap)
+__device__ __forceinline__ unsigned vox_key_of_pt(const VoxGrid& g, const lvi_pt& p)
+{
+    const int ijk0 = (int)sub_rn(floorf(mul_rn(p.x, g.inv)), (float)g.min_b[0]);
+    const int ijk1 = (int)sub_rn(floorf(mul_rn(p.y, g.inv)), (float)g.min_b[1]);
+    const int ijk2 = (int)sub_rn(floorf(mul_rn(p.z, g.inv)), (float)g.min_b[2]);
+    return (unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2;
+}
 __device__ __forceinline__ unsigned vox_key_of(const VoxGrid& g, const lvi_pt* in, const uint8_t* mask, int off, int i)
 {
     if (mask && !mask[off + i]) return g.sentinel;
@@ -275,10 +324,26 @@ __global__ __launch_bounds__(256) void vox_heads_assign_kernel(VoxArgs a)
     }
 }
 
-// pcl::CentroidPoint: f32 sums of x,y,z,intensity over the voxel's points, divided by the count.
-// VOX_CG (8, or 32 for the dense local map) lanes share a voxel: lane i sums points i, i+G, … of the voxel (sorted order = input order, the
-// sort is stable), then the G partial sums are combined in lane order.  For voxels of <= G points this
-// is exactly the sequential sum; for larger ones it is one more of the orders PCL's unstable sort allows.
+// Fixed-point image of one coordinate / the exact mean back in f32 (see the header of this file).
+__device__ __forceinline__ unsigned long long fx_of(float v, float lo, int k)
+{
+    return (unsigned long long)__double2ll_rn(ldexp((double)v - (double)lo, k));
+}
+__device__ __forceinline__ float fx_mean(unsigned long long sum, unsigned cnt, float lo, int k)
+{
+    return (float)((double)lo + ldexp(__ull2double_rn(sum) / (double)cnt, -k));
+}
+__device__ __forceinline__ lvi_pt fx_centroid(const VoxGrid& g, unsigned long long sx, unsigned long long sy, unsigned long long sz,
+                                              unsigned long long si, unsigned cnt)
+{
+    lvi_pt o;
+    o.x = fx_mean(sx, cnt, g.fx_lo[0], g.fx_k); o.y = fx_mean(sy, cnt, g.fx_lo[1], g.fx_k);
+    o.z = fx_mean(sz, cnt, g.fx_lo[2], g.fx_k); o.intensity = fx_mean(si, cnt, g.fx_lo[3], g.fx_ki);
+    return o;
+}
+
+// SORTED path centroid (pcl::CentroidPoint over the voxel's points).  VOX_CG (8, or 32 for the dense local map)
+// lanes share a voxel: lane i sums points i, i+G, … of the voxel, then the partial sums are added up.
 template <int VOX_CG>
 __global__ __launch_bounds__(256) void vox_centroid_kernel(VoxArgs a)
 {
@@ -295,244 +360,404 @@ __global__ __launch_bounds__(256) void vox_centroid_kernel(VoxArgs a)
         const lvi_pt* __restrict__ in = a.st[s].in + a.dyn[s].in_off;
         int b = 0, e = 0;
         if (act) { b = starts[v]; e = starts[v + 1]; }
-        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        if (g.overflow) {                                   // PCL: output = input, untouched
+            if (act && sub == 0) { lvi_pt* out = a.concat ? a.st[0].out : a.st[s].out; out[g.out_off + v] = in[vals[b]]; }
+            continue;
+        }
+        unsigned long long sx = 0, sy = 0, sz = 0, si = 0;
         for (int j = b + sub; j < e; j += VOX_CG) {
             const lvi_pt p = in[vals[j]];
-            sx = add_rn(sx, p.x); sy = add_rn(sy, p.y); sz = add_rn(sz, p.z); si = add_rn(si, p.intensity);
+            sx += fx_of(p.x, g.fx_lo[0], g.fx_k); sy += fx_of(p.y, g.fx_lo[1], g.fx_k);
+            sz += fx_of(p.z, g.fx_lo[2], g.fx_k); si += fx_of(p.intensity, g.fx_lo[3], g.fx_ki);
         }
-        // combine partials in lane order 0,1,…,G-1 (lane 0 ends with the total)
-        float tx = sx, ty = sy, tz = sz, ti = si;
 #pragma unroll
-        for (int q = 1; q < VOX_CG; q++) {
-            const float ox = __shfl_down(sx, q, VOX_CG), oy = __shfl_down(sy, q, VOX_CG), oz = __shfl_down(sz, q, VOX_CG), oi = __shfl_down(si, q, VOX_CG);
-            if (b + q < e) { tx = add_rn(tx, ox); ty = add_rn(ty, oy); tz = add_rn(tz, oz); ti = add_rn(ti, oi); }
+        for (int q = VOX_CG / 2; q > 0; q >>= 1) {
+            sx += __shfl_down(sx, q, VOX_CG); sy += __shfl_down(sy, q, VOX_CG); sz += __shfl_down(sz, q, VOX_CG); si += __shfl_down(si, q, VOX_CG);
         }
         if (act && sub == 0) {
-            const float cnt = (float)(e - b);
-            lvi_pt o;
-            o.x = div_rn(tx, cnt); o.y = div_rn(ty, cnt); o.z = div_rn(tz, cnt); o.intensity = div_rn(ti, cnt);
             lvi_pt* out = a.concat ? a.st[0].out : a.st[s].out;
-            out[g.out_off + v] = o;
+            out[g.out_off + v] = fx_centroid(g, sx, sy, sz, si, (unsigned)(e - b));
         }
     }
 }
 
 // =====================================================================================================
-// Single-workgroup path for tiny plans (capacity <= VOX_SMALL_MAX points per segment).
-// The multi-workgroup pipeline above is 20 launches; with a few thousand points each of them is
-// pure launch latency.  Here ONE 1024-thread workgroup per segment does bbox → geometry → keys → radix
-// sort (only as many 8-bit passes as the key width needs, ping-pong in global scratch that stays in L2)
-// → ordered compaction of the voxel starts; a second small launch writes the centroids (it needs the
-// voxel counts of the preceding segments for the concatenated output).  Same arithmetic, same stable
-// order, therefore the same bits as the large path.
+// BINNED path.  bin = voxel idx >> bin_shift; with a compact grid (div_b product <= VB_NB << VB_CL_LOG) a bin
+// is 1024 consecutive voxel indices and fits LDS; larger grids get wider bins that are swept once per
+// occupied 1024-voxel sub-range.  Nothing is sorted and nothing needs a stable order: integer sums commute.
 // =====================================================================================================
-constexpr int VS_THREADS = 1024;
-constexpr int VS_NW = VS_THREADS / 64;
-constexpr int VS_ITEMS = 4;
-constexpr int VS_TILE = VS_THREADS * VS_ITEMS;
-
-__global__ __launch_bounds__(VS_THREADS) void vox_small_kernel(VoxArgs a)
+// Runs of equal consecutive values across the lanes of a wave (consecutive points of a cloud mostly share a
+// bin / a voxel, and same-address LDS atomics serialise).  head = first lane of its run; hpos = that lane;
+// len (valid on head lanes) = lanes in the run.
+struct WaveRun { bool head; int hpos; int len; };
+__device__ __forceinline__ WaveRun wave_runs(unsigned v)
 {
-    const int s = blockIdx.x, tid = threadIdx.x, w = wave_id(), l = lane_id();
-    __shared__ VoxGrid sg;
-    __shared__ float smn[VS_NW][3], smx[VS_NW][3];
-    __shared__ int scnt[VS_NW];
-    __shared__ unsigned hist[256], dbase[256];
-    __shared__ unsigned waveCnt[VS_NW][256];
-    __shared__ int ws[VS_NW + 2];
-    int n = a.dyn[s].n;
-    n = n < 0 ? 0 : (n > a.seg_cap ? a.seg_cap : n);
-    const int off = a.dyn[s].in_off;
-    const lvi_pt* __restrict__ in = a.st[s].in;
-    const uint8_t* __restrict__ mask = a.st[s].mask;
-    // ---- bbox
-    {
-        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        int cnt = 0;
-        for (int i = tid; i < n; i += VS_THREADS) {
-            if (mask && !mask[off + i]) continue;
-            const lvi_pt p = in[off + i];
-            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-            cnt++;
-        }
-        cnt = wave_sum(cnt);
-#pragma unroll
-        for (int d = 0; d < 3; d++) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
-        if (l == 0) {
-#pragma unroll
-            for (int d = 0; d < 3; d++) { smn[w][d] = mn[d]; smx[w][d] = mx[d]; }
-            scnt[w] = cnt;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int c = 0;
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int q = 0; q < VS_NW; q++) {
-            c += scnt[q];
-#pragma unroll
-            for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], smn[q][d]); hi[d] = fmaxf(hi[d], smx[q][d]); }
-        }
-        sg.n_valid = c;
-#pragma unroll
-        for (int d = 0; d < 3; d++) { sg.bb[d] = c > 0 ? f2ord(lo[d]) : 0xFFFFFFFFu; sg.bb[3 + d] = c > 0 ? f2ord(hi[d]) : 0u; }
-        vox_setup_math(sg, a.st[s].leaf, a.seg_cap);
-        a.d_n[s] = n; a.d_nbits[s] = sg.nbits;
-    }
-    __syncthreads();
-    const size_t so = (size_t)s * a.seg_cap;
-    // ---- keys
-    for (int i = tid; i < n; i += VS_THREADS) { a.keysA[so + i] = vox_key_of(sg, in, mask, off, i); a.valsA[so + i] = (unsigned)i; }
-    __syncthreads();
-    // ---- LSD radix sort, ceil(nbits/8) passes
-    const int npass = (sg.nbits + 7) >> 3;
-    const uint64_t lt = lanemask_lt();
-    for (int pass = 0; pass < npass; pass++) {
-        const int shift = pass * 8;
-        const unsigned* __restrict__ srcK = ((pass & 1) ? a.keysB : a.keysA) + so;
-        const unsigned* __restrict__ srcV = ((pass & 1) ? a.valsB : a.valsA) + so;
-        unsigned* __restrict__ dstK = ((pass & 1) ? a.keysA : a.keysB) + so;
-        unsigned* __restrict__ dstV = ((pass & 1) ? a.valsA : a.valsB) + so;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += VS_THREADS) atomicAdd(&hist[(srcK[i] >> shift) & 255u], 1u);
-        __syncthreads();
-        {
-            int tot;
-            const int ex = block_excl_scan<VS_THREADS>(tid < 256 ? (int)hist[tid] : 0, ws, &tot);
-            if (tid < 256) dbase[tid] = (unsigned)ex;                  // running global base of every digit
-        }
-        __syncthreads();
-        for (int base = 0; base < n; base += VS_TILE) {
-#pragma unroll
-            for (int q = 0; q < VS_NW; q += 4) if (tid < 256) { waveCnt[q][tid] = 0; waveCnt[q + 1][tid] = 0; waveCnt[q + 2][tid] = 0; waveCnt[q + 3][tid] = 0; }
-            __syncthreads();
-            unsigned k[VS_ITEMS], v[VS_ITEMS]; unsigned short r[VS_ITEMS];
-            const int cbase = base + w * (VS_ITEMS * 64);
-#pragma unroll
-            for (int i = 0; i < VS_ITEMS; i++) {
-                const int idx = cbase + i * 64 + l;
-                const bool valid = idx < n;
-                k[i] = valid ? srcK[idx] : 0u; v[i] = valid ? srcV[idx] : 0u;
-                const unsigned d = (k[i] >> shift) & 255u;
-                uint64_t peers = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t m = __ballot(bit); peers &= bit ? m : ~m; }
-                r[i] = 0;
-                if (valid) {
-                    const unsigned prior = waveCnt[w][d];
-                    r[i] = (unsigned short)(prior + __popcll(peers & lt));
-                    if ((peers & lt) == 0) waveCnt[w][d] = prior + __popcll(peers);
-                }
-            }
-            __syncthreads();
-            unsigned tileCnt = 0;
-            if (tid < 256) {                                           // per digit: offsets of the waves inside the tile
-#pragma unroll
-                for (int q = 0; q < VS_NW; q++) { const unsigned c = waveCnt[q][tid]; waveCnt[q][tid] = tileCnt; tileCnt += c; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < VS_ITEMS; i++) {
-                const int idx = cbase + i * 64 + l;
-                if (idx < n) {
-                    const unsigned d = (k[i] >> shift) & 255u;
-                    const unsigned g = dbase[d] + waveCnt[w][d] + r[i];
-                    dstK[g] = k[i]; dstV[g] = v[i];
-                }
-            }
-            __syncthreads();
-            if (tid < 256) dbase[tid] += tileCnt;
-            __syncthreads();
-        }
-    }
-    // ---- voxel starts: ordered compaction of the first entry of every distinct key
-    const unsigned* keys = ((npass & 1) ? a.keysB : a.keysA) + so;
-    int* starts = a.starts + (size_t)s * ((size_t)a.seg_cap + 1);
-    const unsigned sent = sg.sentinel;
-    int carry = 0, first_sent = n;
-    for (int base = 0; base < n; base += VS_TILE) {
-        bool h[VS_ITEMS]; int c = 0;
-#pragma unroll
-        for (int j = 0; j < VS_ITEMS; j++) { const int i = base + tid * VS_ITEMS + j; h[j] = (i < n) && is_head(keys, i, sent); c += h[j]; }
-        int tot;
-        int vv = carry + block_excl_scan<VS_THREADS>(c, ws, &tot);
-#pragma unroll
-        for (int j = 0; j < VS_ITEMS; j++) {
-            const int i = base + tid * VS_ITEMS + j;
-            if (i >= n) break;
-            if (h[j]) starts[vv++] = i;
-            if (keys[i] == sent && (i == 0 || keys[i - 1] != sent)) first_sent = i;
-        }
-        carry += tot;
-    }
-    // end of the last voxel = first masked-out entry (at most one thread found it), else n
-    __shared__ int s_end;
-    if (tid == 0) s_end = n;
-    __syncthreads();
-    if (first_sent < n) s_end = first_sent;
-    __syncthreads();
-    if (tid == 0) {
-        starts[carry] = s_end;
-        sg.nvox = carry;
-        a.grid[s] = sg;
-    }
+    const int l = lane_id();
+    const unsigned prev = __shfl_up(v, 1, 64);
+    WaveRun r;
+    r.head = l == 0 || prev != v;
+    const uint64_t hm = __ballot(r.head);
+    r.hpos = 63 - __clzll(hm & ((2ull << l) - 1ull));
+    const uint64_t above = l == 63 ? 0ull : hm & ~((2ull << l) - 1ull);
+    r.len = (above ? __ffsll((unsigned long long)above) - 1 : 64) - l;
+    return r;
 }
 
-// out offsets of the concatenated output + centroids, 8 lanes per voxel (as vox_centroid_kernel<8>)
-__global__ __launch_bounds__(VS_THREADS) void vox_small_finish_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_hist_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const int n = a.d_n[s];
+    const int base = blockIdx.x * VB_TILE;
+    const VoxGrid& g = a.grid[s];
+    if (base >= n || g.nbins == 0) return;
+    __shared__ unsigned cnt[VB_NB];
+    const int nbins = g.nbins, sh = g.bin_shift;
+    for (int b = threadIdx.x; b < nbins; b += 256) cnt[b] = 0u;
+    __syncthreads();
+    const int off = a.dyn[s].in_off;
+    const lvi_pt* __restrict__ in = a.st[s].in + off;
+    const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+#pragma unroll 4
+    for (int u = 0; u < VB_TILE / 256; u++) {
+        const int i = base + u * 256 + threadIdx.x;
+        const bool ok = i < n && (!mask || mask[i]);
+        const unsigned bin = ok ? vox_key_of_pt(g, in[i]) >> sh : 0xFFFFFFFFu;
+        const WaveRun r = wave_runs(bin);
+        if (ok && r.head) atomicAdd(&cnt[bin], (unsigned)r.len);
+    }
+    __syncthreads();
+    unsigned* gc = a.binCount + (size_t)s * VB_NB;
+    for (int b = threadIdx.x; b < nbins; b += 256) { const unsigned c = cnt[b]; if (c) atomicAdd(&gc[b], c); }
+}
+
+// per segment: binStart = exclusive scan of binCount, cursor = binStart, binCount back to zero
+__global__ __launch_bounds__(256) void vb_scan_kernel(VoxArgs a)
 {
     const int s = blockIdx.x;
-    __shared__ int s_off;
-    if (threadIdx.x == 0) {
-        int off = 0, total = 0;
-        for (int q = 0; q < a.nseg; q++) { if (q < s) off += a.grid[q].nvox; total += a.grid[q].nvox; }
-        s_off = a.concat ? off : 0;
-        a.grid[s].out_off = s_off;
-        a.nout[s] = a.grid[s].nvox;
-        if (s == 0) a.nout[a.nseg] = total;
+    const int nbins = a.grid[s].nbins;
+    unsigned* gc = a.binCount + (size_t)s * VB_NB;
+    int* bs = a.binStart + (size_t)s * (VB_NB + 1);
+    unsigned* cur = a.cursor + (size_t)s * VB_NB;
+    __shared__ int ws[8];
+    constexpr int PER = VB_NB / 256;                    // consecutive bins per thread
+    int v[PER], sum = 0, csum = 0, msum = 0;
+    const bool wide = a.grid[s].bin_shift > VB_CL_LOG;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int b = threadIdx.x * PER + j;
+        v[j] = b < nbins ? (int)gc[b] : 0;
+        sum += v[j];
+        const int nch = wide ? (v[j] > 0) : (v[j] + VB_CH - 1) / VB_CH;
+        csum += nch; msum += nch > 1 ? nch : 0;
+    }
+    int tot, ctot, mtot;
+    int ex = block_excl_scan<256>(sum, ws, &tot);
+    int cex = block_excl_scan<256>(csum, ws, &ctot);
+    int mex = block_excl_scan<256>(msum, ws, &mtot);
+    int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
+    int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int b = threadIdx.x * PER + j;
+        if (b < nbins) { bs[b] = ex; cur[b] = (unsigned)ex; gc[b] = 0u; cs[b] = cex; ms[b] = mex; a.binVox[(size_t)s * VB_NB + b] = 0; }
+        ex += v[j];
+        const int nch = wide ? (v[j] > 0) : (v[j] + VB_CH - 1) / VB_CH;
+        cex += nch; mex += nch > 1 ? nch : 0;
+    }
+    if (threadIdx.x == 0) { bs[nbins] = tot; cs[nbins] = ctot; ms[nbins] = mtot; }
+}
+
+__global__ __launch_bounds__(256) void vb_scatter_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const int n = a.d_n[s];
+    const int base = blockIdx.x * VB_TILE;
+    const VoxGrid& g = a.grid[s];
+    if (base >= n || g.nbins == 0) return;
+    __shared__ unsigned cnt[VB_NB];
+    const int nbins = g.nbins, sh = g.bin_shift;
+    for (int b = threadIdx.x; b < nbins; b += 256) cnt[b] = 0u;
+    __syncthreads();
+    const int off = a.dyn[s].in_off;
+    const lvi_pt* __restrict__ in = a.st[s].in + off;
+    const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+    constexpr int IT = VB_TILE / 256;
+    lvi_pt p[IT]; int bin[IT]; unsigned rk[IT];
+#pragma unroll
+    for (int u = 0; u < IT; u++) {
+        const int i = base + u * 256 + threadIdx.x;
+        bin[u] = -1;
+        if (i < n && (!mask || mask[i])) { p[u] = in[i]; bin[u] = (int)(vox_key_of_pt(g, p[u]) >> sh); }
+    }
+#pragma unroll
+    for (int u = 0; u < IT; u++) {                      // rank inside (tile, bin): any order will do; one LDS atomic per run
+        const WaveRun r = wave_runs((unsigned)bin[u]);
+        unsigned b0 = 0u;
+        if (bin[u] >= 0 && r.head) b0 = atomicAdd(&cnt[bin[u]], (unsigned)r.len);
+        rk[u] = __shfl(b0, r.hpos, 64) + (unsigned)(lane_id() - r.hpos);
     }
     __syncthreads();
-    const int out_off = s_off;
-    const int nvox = a.grid[s].nvox;
-    constexpr int G = 8;
-    const int sub = threadIdx.x % G;
-    const int* starts = a.starts + (size_t)s * ((size_t)a.seg_cap + 1);
-    const unsigned* vals = sorted_vals(a, s);
-    const lvi_pt* __restrict__ in = a.st[s].in + a.dyn[s].in_off;
-    lvi_pt* out = a.concat ? a.st[0].out : a.st[s].out;
-    for (int v0 = 0; v0 < nvox; v0 += VS_THREADS / G) {
-        const int v = v0 + threadIdx.x / G;
-        const bool act = v < nvox;
-        int b = 0, e = 0;
-        if (act) { b = starts[v]; e = starts[v + 1]; }
-        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-        for (int j = b + sub; j < e; j += G) {
-            const lvi_pt p = in[vals[j]];
-            sx = add_rn(sx, p.x); sy = add_rn(sy, p.y); sz = add_rn(sz, p.z); si = add_rn(si, p.intensity);
-        }
-        float tx = sx, ty = sy, tz = sz, ti = si;
+    unsigned* cur = a.cursor + (size_t)s * VB_NB;
+    for (int b = threadIdx.x; b < nbins; b += 256) { const unsigned c = cnt[b]; if (c) cnt[b] = atomicAdd(&cur[b], c); }
+    __syncthreads();
+    lvi_pt* __restrict__ dst = a.bucketed + (size_t)s * a.seg_cap;
 #pragma unroll
-        for (int q = 1; q < G; q++) {
-            const float ox = __shfl_down(sx, q, G), oy = __shfl_down(sy, q, G), oz = __shfl_down(sz, q, G), oi = __shfl_down(si, q, G);
-            if (b + q < e) { tx = add_rn(tx, ox); ty = add_rn(ty, oy); tz = add_rn(tz, oz); ti = add_rn(ti, oi); }
+    for (int u = 0; u < IT; u++) if (bin[u] >= 0) dst[cnt[bin[u]] + rk[u]] = p[u];
+}
+
+// LDS accumulators of one sweep: up to 1024 consecutive voxels
+struct VbCells {
+    unsigned long long sx[1 << VB_CL_LOG], sy[1 << VB_CL_LOG], sz[1 << VB_CL_LOG], si[1 << VB_CL_LOG];
+    unsigned cn[1 << VB_CL_LOG];
+};
+
+__device__ __forceinline__ void vb_zero(VbCells& L, int cells)
+{
+    for (int c = threadIdx.x; c < cells; c += 256) { L.sx[c] = 0ull; L.sy[c] = 0ull; L.sz[c] = 0ull; L.si[c] = 0ull; L.cn[c] = 0u; }
+    __syncthreads();
+}
+
+// add bucketed points [q0, q1) whose voxel idx lies in [k0, k0 + cells) to the LDS accumulators
+__device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, const lvi_pt* __restrict__ pts, int q0, int q1, unsigned k0, int cells)
+{
+    for (int i0 = q0 + threadIdx.x; i0 < q1; i0 += 4 * 256) {
+        lvi_pt p[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ok[u] = i0 + u * 256 < q1; if (ok[u]) p[u] = pts[i0 + u * 256]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!ok[u]) continue;
+            const unsigned c = vox_key_of_pt(g, p[u]) - k0;
+            if (c >= (unsigned)cells) continue;                         // another sub-range of a wide bin
+            atomicAdd(&L.sx[c], fx_of(p[u].x, g.fx_lo[0], g.fx_k)); atomicAdd(&L.sy[c], fx_of(p[u].y, g.fx_lo[1], g.fx_k));
+            atomicAdd(&L.sz[c], fx_of(p[u].z, g.fx_lo[2], g.fx_k)); atomicAdd(&L.si[c], fx_of(p[u].intensity, g.fx_lo[3], g.fx_ki));
+            atomicAdd(&L.cn[c], 1u);
         }
-        if (act && sub == 0) {
-            const float cnt = (float)(e - b);
-            lvi_pt o;
-            o.x = div_rn(tx, cnt); o.y = div_rn(ty, cnt); o.z = div_rn(tz, cnt); o.intensity = div_rn(ti, cnt);
-            out[out_off + v] = o;
+    }
+    __syncthreads();
+}
+
+// ordered compaction of the occupied voxels of the sweep into the staging area (thread t owns voxels 4t..4t+3);
+// returns the number written
+__device__ __forceinline__ int vb_emit(const VbCells& L, const VoxGrid& g, lvi_pt* __restrict__ stg, uint2* __restrict__ skc, int at, unsigned k0, int cells, int* ws)
+{
+    const int tid = threadIdx.x;
+    int c4 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int c = tid * 4 + j; c4 += c < cells && L.cn[c] != 0u; }
+    int tot;
+    int r = at + block_excl_scan<256>(c4, ws, &tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = tid * 4 + j;
+        const unsigned m = c < cells ? L.cn[c] : 0u;
+        if (m) { stg[r] = fx_centroid(g, L.sx[c], L.sy[c], L.sz[c], L.si[c], m); skc[r] = make_uint2(k0 + (unsigned)c, m); r++; }
+    }
+    __syncthreads();
+    return tot;
+}
+
+// One workgroup per chunk of <= VB_CH bucketed points of one bin.  A bin that is a single chunk is finished here;
+// the chunks of a larger bin leave their LDS tables in chunkTab and vb_merge adds them up (no global atomics,
+// so a bin with 10^5 points is spread over 25 workgroups instead of keeping one busy for 0.2 ms).
+__global__ __launch_bounds__(256) void vb_accum_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const VoxGrid& g = a.grid[s];
+    const int nbins = g.nbins, sh = g.bin_shift;
+    if (nbins == 0) return;
+    __shared__ VbCells L;
+    __shared__ unsigned occ[1024];                                          // occupied sub-ranges of a wide bin
+    static_assert(VB_NB == 4096 && VB_CL_LOG == 10, "occ[] is sized for 2^32 / VB_NB / 2^VB_CL_LOG sub-ranges");
+    __shared__ int ws[8];
+    const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
+    const int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
+    const int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
+    const lvi_pt* __restrict__ pts = a.bucketed + (size_t)s * a.seg_cap;
+    lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
+    uint2* __restrict__ skc = a.stagingKC + (size_t)s * a.seg_cap;
+    const int tid = threadIdx.x;
+    const int nchunks = cs[nbins];
+    const int cells = sh >= VB_CL_LOG ? (1 << VB_CL_LOG) : (1 << sh);
+    for (int w = blockIdx.x; w < nchunks; w += gridDim.x) {
+        int lo = 0, hi = nbins;                                             // last bin with chunkStart <= w
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cs[mid] <= w) lo = mid; else hi = mid; }
+        const int b = lo;
+        const int j = w - cs[b], nch = cs[b + 1] - cs[b];
+        const int p0 = bs[b], p1 = bs[b + 1];
+        const unsigned kbase = (unsigned)b << sh;
+        if (sh > VB_CL_LOG) {
+            // wide bin (sparse grid): one workgroup, one sweep per occupied 1024-voxel sub-range
+            const int nsub = 1 << (sh - VB_CL_LOG);
+            for (int q = tid; q < nsub; q += 256) occ[q] = 0u;
+            __syncthreads();
+            for (int i = p0 + tid; i < p1; i += 256) occ[(vox_key_of_pt(g, pts[i]) - kbase) >> VB_CL_LOG] = 1u;
+            __syncthreads();
+            int carry = 0;
+            for (int sp = 0; sp < nsub; sp++) {
+                if (!occ[sp]) continue;                                     // same for every thread
+                const unsigned k0 = kbase + ((unsigned)sp << VB_CL_LOG);
+                vb_zero(L, cells);
+                vb_add_points(L, g, pts, p0, p1, k0, cells);
+                carry += vb_emit(L, g, stg, skc, p0 + carry, k0, cells, ws);
+            }
+            if (tid == 0) a.binVox[(size_t)s * VB_NB + b] = carry;
+            continue;
         }
+        const int q0 = p0 + j * VB_CH, q1 = min(p1, q0 + VB_CH);
+        vb_zero(L, cells);
+        vb_add_points(L, g, pts, q0, q1, kbase, cells);
+        if (nch == 1) {
+            const int tot = vb_emit(L, g, stg, skc, p0, kbase, cells, ws);
+            if (tid == 0) a.binVox[(size_t)s * VB_NB + b] = tot;
+        } else {
+            // leave the table in global memory for vb_merge.  (Letting the workgroup that finishes a bin's last chunk add
+            // them up needs a device-scope fence per chunk; on a multi-XCD part every such fence writes back and invalidates
+            // the XCD's L2 — measured 257 us instead of 41 + 19 us for the 4.9M-point map.)
+            unsigned long long* tv = a.chunkTabV + ((size_t)s * a.max_multi + ms[b] + j) * (size_t)(4 << VB_CL_LOG);
+            unsigned* tc = a.chunkTabC + ((size_t)s * a.max_multi + ms[b] + j) * (size_t)(1 << VB_CL_LOG);
+            for (int c = tid; c < cells; c += 256) {
+                tv[c] = L.sx[c]; tv[cells + c] = L.sy[c]; tv[2 * cells + c] = L.sz[c]; tv[3 * cells + c] = L.si[c]; tc[c] = L.cn[c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// bins of more than one chunk: add the chunk tables up and emit
+__global__ __launch_bounds__(256) void vb_merge_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const VoxGrid& g = a.grid[s];
+    const int nbins = g.nbins, sh = g.bin_shift;
+    if (nbins == 0 || sh > VB_CL_LOG) return;
+    __shared__ VbCells L;
+    __shared__ int ws[8];
+    const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
+    const int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
+    const int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
+    lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
+    uint2* __restrict__ skc = a.stagingKC + (size_t)s * a.seg_cap;
+    const int cells = 1 << sh;
+    for (int b = blockIdx.x; b < nbins; b += gridDim.x) {
+        const int nch = cs[b + 1] - cs[b];
+        if (nch <= 1) continue;
+        const size_t t0 = (size_t)s * a.max_multi + ms[b];
+        for (int c = threadIdx.x; c < cells; c += 256) {
+            unsigned long long x = 0, y = 0, z = 0, w = 0; unsigned m = 0;
+#pragma unroll 4
+            for (int j = 0; j < nch; j++) {
+                const unsigned long long* tv = a.chunkTabV + (t0 + j) * (size_t)(4 << VB_CL_LOG);
+                const unsigned* tc = a.chunkTabC + (t0 + j) * (size_t)(1 << VB_CL_LOG);
+                x += tv[c]; y += tv[cells + c]; z += tv[2 * cells + c]; w += tv[3 * cells + c]; m += tc[c];
+            }
+            L.sx[c] = x; L.sy[c] = y; L.sz[c] = z; L.si[c] = w; L.cn[c] = m;
+        }
+        __syncthreads();
+        const int tot = vb_emit(L, g, stg, skc, bs[b], (unsigned)b << sh, cells, ws);
+        if (threadIdx.x == 0) a.binVox[(size_t)s * VB_NB + b] = tot;
+    }
+}
+
+// binOut = exclusive scan of binVox per segment; voxel counts and output offsets of the batch
+__global__ __launch_bounds__(256) void vb_outscan_kernel(VoxArgs a)
+{
+    __shared__ int ws[8];
+    constexpr int PER = VB_NB / 256;
+    for (int s = 0; s < a.nseg; s++) {
+        const VoxGrid& g = a.grid[s];
+        const int nbins = g.nbins;
+        const int* bv = a.binVox + (size_t)s * VB_NB;
+        int* bo = a.binOut + (size_t)s * VB_NB;
+        int v[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { const int b = threadIdx.x * PER + j; v[j] = b < nbins ? bv[b] : 0; sum += v[j]; }
+        int tot;
+        int ex = block_excl_scan<256>(sum, ws, &tot);
+#pragma unroll
+        for (int j = 0; j < PER; j++) { const int b = threadIdx.x * PER + j; if (b < nbins) bo[b] = ex; ex += v[j]; }
+        if (threadIdx.x == 0) a.grid[s].nvox = g.overflow ? g.n_valid : tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int s = 0; s < a.nseg; s++) {
+            a.grid[s].out_off = a.concat ? off : 0;
+            a.nout[s] = a.grid[s].nvox;
+            off += a.grid[s].nvox;
+        }
+        a.nout[a.nseg] = off;
+    }
+}
+
+__global__ __launch_bounds__(256) void vb_copy_kernel(VoxArgs a)
+{
+    const int s = blockIdx.y;
+    const VoxGrid& g = a.grid[s];
+    lvi_pt* __restrict__ out = (a.concat ? a.st[0].out : a.st[s].out) + g.out_off;
+    const int tid = threadIdx.x;
+    if (!g.overflow) {
+        const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
+        const int* bv = a.binVox + (size_t)s * VB_NB;
+        const int* bo = a.binOut + (size_t)s * VB_NB;
+        const lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
+        for (int b = blockIdx.x; b < g.nbins; b += gridDim.x) {
+            const int nv = bv[b], src = bs[b], dst = bo[b];
+            for (int j = tid; j < nv; j += 256) out[dst + j] = stg[src + j];
+        }
+        return;
+    }
+    // PCL's overflow rule: output = the segment's (unmasked) input points, in input order
+    const int n = a.d_n[s];
+    const int off = a.dyn[s].in_off;
+    const lvi_pt* __restrict__ in = a.st[s].in + off;
+    const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+    const int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = min(n, (int)blockIdx.x * chunk), i1 = min(n, i0 + chunk);
+    if (i0 >= i1) return;
+    __shared__ int ws[8];
+    int basep = i0;
+    if (mask) {
+        int c = 0;
+        for (int i = tid; i < i0; i += 256) c += mask[i] != 0;
+        int tot;
+        (void)block_excl_scan<256>(c, ws, &tot);
+        basep = tot;
+    }
+    for (int i = i0; i < i1; i += 256) {
+        const int j = i + tid;
+        const bool keep = j < i1 && (!mask || mask[j]);
+        int tot;
+        const int r = block_excl_scan<256>(keep ? 1 : 0, ws, &tot);
+        if (keep) out[basep + r] = in[j];
+        basep += tot;
     }
 }
 
 }  // namespace
 
-void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs) const
+static VoxArgs make_args(const VoxelPlan& p)
 {
+    return VoxArgs{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
+                   p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm,
+                   p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
+                   p.d_chunkStart, p.d_multiStart, p.d_chunkTabV, p.d_chunkTabC, p.max_multi};
+}
+
+void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs)
+{
+    if (!h_ncells) {
+        LVI_HIP(hipHostMalloc((void**)&h_ncells, sizeof(unsigned long long) * nseg, hipHostMallocDefault));
+        for (int s = 0; s < nseg; s++) h_ncells[s] = ~0ull;           // unknown: AUTO starts with the sorted path
+    }
     LVI_HIP(hipMemcpyAsync(d_static, host_segs, sizeof(VoxSegStatic) * nseg, hipMemcpyHostToDevice, ctx.stream));
     LVI_HIP(hipStreamSynchronize(ctx.stream));
+}
+
+void VoxelPlan::release()
+{
+    if (h_ncells) (void)hipHostFree(h_ncells);
+    h_ncells = nullptr;
 }
 
 // Debug view of segment 0 of the last run (tests only): per-input-point keys, distinct keys in
@@ -544,17 +769,28 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
     LVI_HIP(hipMemcpyAsync(&g, p.d_grid, sizeof(g), hipMemcpyDeviceToHost, ctx.stream));
     LVI_HIP(hipStreamSynchronize(ctx.stream));
     if (g.overflow || n_in <= 0 || g.n_valid == 0) return;
-    const bool inB = (((g.nbits + 7) >> 3) & 1) != 0;
-    std::vector<unsigned> sk(n_in);
-    std::vector<int> st(g.nvox + 1);
-    LVI_HIP(hipMemcpyAsync(sk.data(), inB ? p.sort.keysB : p.sort.keysA, sizeof(unsigned) * n_in, hipMemcpyDeviceToHost, ctx.stream));
-    LVI_HIP(hipMemcpyAsync(st.data(), p.d_starts, sizeof(int) * (g.nvox + 1), hipMemcpyDeviceToHost, ctx.stream));
-    LVI_HIP(hipStreamSynchronize(ctx.stream));
     cells.resize(g.nvox); counts.resize(g.nvox);
-    for (int v = 0; v < g.nvox; v++) { cells[v] = (int32_t)sk[st[v]]; counts[v] = st[v + 1] - st[v]; }
+    if (p.last_mode == VOX_BINNED) {
+        std::vector<int> bs(g.nbins + 1), bv(g.nbins);
+        std::vector<uint2> kc(n_in);
+        LVI_HIP(hipMemcpyAsync(bs.data(), p.d_binStart, sizeof(int) * (g.nbins + 1), hipMemcpyDeviceToHost, ctx.stream));
+        LVI_HIP(hipMemcpyAsync(bv.data(), p.d_binVox, sizeof(int) * g.nbins, hipMemcpyDeviceToHost, ctx.stream));
+        LVI_HIP(hipMemcpyAsync(kc.data(), p.d_stagingKC, sizeof(uint2) * n_in, hipMemcpyDeviceToHost, ctx.stream));
+        LVI_HIP(hipStreamSynchronize(ctx.stream));
+        int v = 0;
+        for (int b = 0; b < g.nbins; b++)
+            for (int j = 0; j < bv[b] && v < g.nvox; j++, v++) { cells[v] = (int32_t)kc[bs[b] + j].x; counts[v] = (int32_t)kc[bs[b] + j].y; }
+    } else {
+        const bool inB = (((g.nbits + 7) >> 3) & 1) != 0;
+        std::vector<unsigned> sk(n_in);
+        std::vector<int> st(g.nvox + 1);
+        LVI_HIP(hipMemcpyAsync(sk.data(), inB ? p.sort.keysB : p.sort.keysA, sizeof(unsigned) * n_in, hipMemcpyDeviceToHost, ctx.stream));
+        LVI_HIP(hipMemcpyAsync(st.data(), p.d_starts, sizeof(int) * (g.nvox + 1), hipMemcpyDeviceToHost, ctx.stream));
+        LVI_HIP(hipStreamSynchronize(ctx.stream));
+        for (int v = 0; v < g.nvox; v++) { cells[v] = (int32_t)sk[st[v]]; counts[v] = st[v + 1] - st[v]; }
+    }
     // per-point keys: recompute into keysA (scratch is free once the outputs are written)
-    VoxArgs a{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
-              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm};
+    const VoxArgs a = make_args(p);
     hipLaunchKernelGGL(vox_keys_kernel, dim3(div_up(n_in, 256), 1), dim3(256), 0, ctx.stream, a);
     LVI_HIP(hipGetLastError());
     keys.resize(n_in);
@@ -564,33 +800,46 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
 
 void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
 {
-    VoxArgs a{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
-              p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm};
-    if (p.seg_cap <= VOX_SMALL_MAX) {
-        char n0[48], n1[48];
-        snprintf(n0, sizeof(n0), "vox_small/%s", tag); snprintf(n1, sizeof(n1), "vox_small_finish/%s", tag);
-        LVI_LAUNCH(ctx, n0, 16.0 * n_hint, hipLaunchKernelGGL(vox_small_kernel, dim3(p.nseg), dim3(VS_THREADS), 0, ctx.stream, a));
-        LVI_LAUNCH(ctx, n1, 20.0 * n_hint, hipLaunchKernelGGL(vox_small_finish_kernel, dim3(p.nseg), dim3(VS_THREADS), 0, ctx.stream, a));
+    const VoxArgs a = make_args(p);
+    int mode = p.mode;
+    if (mode == VOX_AUTO) {
+        // hint of the previous batch of this plan (pinned host memory written by vox_setup; a racing read returns the
+        // older or the newer value, and either path is correct for any grid)
+        mode = VOX_BINNED;
+        for (int s = 0; s < p.nseg; s++)
+            if (!p.h_ncells || p.h_ncells[s] > ((unsigned long long)VB_NB << VB_CL_LOG)) mode = VOX_SORTED;
+    }
+    p.last_mode = mode;
+    char nm[16][48];
+    const char* base[16] = {"vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid",
+                            "vb_hist", "vb_scan", "vb_scatter", "vb_accum", "vb_outscan", "vb_copy", "vb_merge", "", ""};
+    for (int i = 0; i < 14; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
+    LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg), dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg), dim3(64), 0, ctx.stream, a));
+    if (mode == VOX_BINNED) {
+        const dim3 gt(div_up(p.seg_cap, VB_TILE), p.nseg);
+        const dim3 gb(std::min(VB_ACC_BLOCKS, VB_NB), p.nseg);
+        LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gt, dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg), dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, a));
+        const dim3 ga(std::max(128, std::min(2 * div_up(p.seg_cap, VB_CH), 2048)), p.nseg);      // grid-stride over the chunks
+        LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel, ga, dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, gb, dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[11], 0, hipLaunchKernelGGL(vb_outscan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[12], 0, hipLaunchKernelGGL(vb_copy_kernel, gb, dim3(256), 0, ctx.stream, a));
         return;
     }
-    char nm[8][48];
-    const char* base[8] = {"vox_init", "vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid"};
-    for (int i = 0; i < 8; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
-    const int mm_blocks = p.nblk_mm;
     const dim3 gp(div_up(p.seg_cap, 256), p.nseg), gh(p.nblk_h, p.nseg);
-    LVI_LAUNCH(ctx, nm[0], 0, hipLaunchKernelGGL(vox_init_kernel, dim3(1), dim3(64), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[1], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(mm_blocks, p.nseg), dim3(256), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[2], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg), dim3(64), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[3], 24.0 * n_hint, hipLaunchKernelGGL(vox_keys_kernel, gp, dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[2], 24.0 * n_hint, hipLaunchKernelGGL(vox_keys_kernel, gp, dim3(256), 0, ctx.stream, a));
     radix_sort_pairs(ctx, p.sort, p.d_n, p.d_nbits, 4, tag, n_hint);
-    LVI_LAUNCH(ctx, nm[4], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_count_kernel, gh, dim3(256), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[5], 0, hipLaunchKernelGGL(vox_heads_scan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[6], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_assign_kernel, gh, dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[3], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_count_kernel, gh, dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[4], 0, hipLaunchKernelGGL(vox_heads_scan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[5], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_assign_kernel, gh, dim3(256), 0, ctx.stream, a));
     const dim3 gc(std::max(1, std::min(div_up(p.seg_cap, 256 / 8), 8192)), p.nseg);
     if (p.centroid_lanes >= 32)
-        LVI_LAUNCH(ctx, nm[7], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<32>, gc, dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[6], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<32>, gc, dim3(256), 0, ctx.stream, a));
     else
-        LVI_LAUNCH(ctx, nm[7], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<8>, gc, dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[6], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<8>, gc, dim3(256), 0, ctx.stream, a));
 }
 
 }  // namespace lvi

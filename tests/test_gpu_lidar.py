@@ -18,10 +18,11 @@ def scene(pkg, oracle):
     return make_small_scene(pkg, oracle)
 
 
-@pytest.fixture()
-def pair(pkg, oracle, hip):
+@pytest.fixture(params=[1, 2], ids=["vox_sorted", "vox_binned"])
+def pair(request, pkg, oracle, hip):
+    """every test that takes `pair` runs once per realisation of the voxel grids (lvi_lidar_params.voxel_mode)"""
     o = pkg.LidarHotpath(oracle, **small_params())
-    g = pkg.LidarHotpath(hip, **small_params())
+    g = pkg.LidarHotpath(hip, voxel_mode=request.param, **small_params())
     yield o, g
     o.close(); g.close()
 
@@ -126,7 +127,10 @@ def _voxel_case(pkg, o, g, pts, leaf):
     cnt = o.debug_get(A.DBG_VOXEL_COUNTS, np.int32)
     np.testing.assert_array_equal(cnt, g.debug_get(A.DBG_VOXEL_COUNTS, np.int32))
     assert len(vo) == len(vg)
-    if len(vo):
+    if len(vo) and len(cnt) == 0:                      # PCL's overflow rule fired: output = input, bit for bit
+        np.testing.assert_array_equal(xyzi(vo).view(np.uint32), xyzi(vg).view(np.uint32))
+        np.testing.assert_array_equal(xyzi(vg).view(np.uint32), np.asarray(pts, np.float32).view(np.uint32))
+    elif len(vo):
         assert np.all(np.abs(xyzi(vo).astype(np.float64) - xyzi(vg)) <= centroid_tol(cnt, vo))
     return len(vo)
 
@@ -146,21 +150,41 @@ def test_voxel_downsample_keys_bit_exact(pkg, pair):
     _voxel_case(pkg, o, g, -np.abs(c), 0.2)
 
 
-def test_voxel_single_workgroup_path(pkg, oracle, hip):
-    """capacities <= 4096 take the one-workgroup-per-segment voxel kernels: same keys, cells, counts"""
-    kw = dict(N_SCAN=4, Horizon_SCAN=1000, max_raw_points=4096, max_map_points=4096)
-    o = pkg.LidarHotpath(oracle, **kw); g = pkg.LidarHotpath(hip, **kw)
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["vox_auto", "vox_sorted", "vox_binned"])
+def test_voxel_modes_ragged_sizes_and_sparse_grids(pkg, oracle, hip, mode):
+    """ragged sizes around the wave / tile boundaries, compact grids (1024-voxel bins), sparse huge grids (wide bins
+    swept per occupied sub-range) and the overflow rule, per realisation; auto switches after the first batch"""
+    kw = dict(N_SCAN=4, Horizon_SCAN=1000, max_raw_points=4096, max_map_points=20000)
+    o = pkg.LidarHotpath(oracle, **kw); g = pkg.LidarHotpath(hip, voxel_mode=mode, **kw)
     rng = np.random.default_rng(21)
-    for n in (1, 2, 63, 64, 65, 1023, 1024, 1025, 4096):
+    for n in (1, 2, 63, 64, 65, 1023, 1024, 1025, 4096, 4097, 20000):
         pts = np.zeros((n, 4), np.float32)
         pts[:, :3] = rng.uniform(-25, 25, (n, 3)) * [1, 1, 0.2]
         pts[:, 3] = rng.uniform(0, 255, n)
-        for leaf in (0.4, 0.1, 3.0):
+        for leaf in (0.4, 0.1, 3.0, 0.02):
             _voxel_case(pkg, o, g, pts, leaf)
+    # scan-line order (runs of points in the same voxel, as in a keyframe cloud) and a constant intensity
+    t = np.linspace(0, 40, 20000, dtype=np.float32)
+    line = np.stack([t - 20, np.sin(t) * 5, 0.1 * t, np.full_like(t, 3.0)], axis=1).astype(np.float32)
+    assert _voxel_case(pkg, o, g, line, 0.4) > 50
     far = np.array([[0, 0, 0, 1], [3000, 3000, 3000, 2], [1, 1, 1, 3]], np.float32)
     np.testing.assert_array_equal(xyzi(g.voxel_downsample(far, 0.01)), far)
     assert len(g.voxel_downsample(np.zeros((0, 4), np.float32), 0.4)) == 0
     o.close(); g.close()
+
+
+def test_voxel_modes_give_identical_bits(pkg, hip):
+    """integer sums commute: the sorted and the binned realisation return the same floats"""
+    kw = dict(N_SCAN=4, Horizon_SCAN=1000, max_raw_points=4096, max_map_points=60000)
+    a = pkg.LidarHotpath(hip, voxel_mode=1, **kw); b = pkg.LidarHotpath(hip, voxel_mode=2, **kw)
+    rng = np.random.default_rng(5)
+    pts = np.zeros((60000, 4), np.float32)
+    pts[:, :3] = rng.normal(0, 6, (60000, 3)) * [1, 1, 0.2]
+    pts[:, 3] = rng.uniform(-5, 300, 60000)
+    for leaf in (0.4, 0.2, 0.03):
+        ra, rb = xyzi(a.voxel_downsample(pts, leaf)), xyzi(b.voxel_downsample(pts, leaf))
+        np.testing.assert_array_equal(ra.view(np.uint32), rb.view(np.uint32))
+    a.close(); b.close()
 
 
 def test_voxel_downsample_edge_cases(pkg, pair):
@@ -215,13 +239,16 @@ def test_map_build_and_knn_exact(pkg, pair, scene):
 
 
 def test_knn_index_bit_exact_on_identical_map(pkg, oracle, hip):
-    """integer-valued map coordinates → both voxel paths give identical centroids → KNN must match exactly"""
+    """one map point per voxel → oracle (f32 running sums) and HIP (exact mean) give identical centroids → KNN must match exactly"""
     rng = np.random.default_rng(11)
     P = small_params()
     o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P)
     m = np.zeros((60000, 4), np.float32)
     m[:, :3] = (rng.integers(-200, 200, (60000, 3)) * 0.25 + 0.125) * [1, 1, 0.2]      # one point per 0.2-voxel at most twice
     m = np.unique(m, axis=0)
+    _, first = np.unique(np.floor(m[:, :3] / np.float32(0.4)).astype(np.int64), axis=0, return_index=True)
+    m = m[np.sort(first)]                                                               # at most one point per 0.4-voxel (and per 0.2-voxel)
+    assert len(m) > 20000
     for h in (o, g):
         h.map_set(m, m)
     (mco, mso), (mcg, msg) = o.get_map_ds(), g.get_map_ds()

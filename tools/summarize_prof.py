@@ -72,27 +72,33 @@ def steady(d, out, nsteps):
     print(open(out).read())
 
 
-def pmc(fd, wd, out):
+def pmc(fd, wd, out, nsteps=3):
+    """HBM bytes per launch per kernel AND launch geometry, over the last nsteps bench steps (a step ends with
+    icp_finish_kernel).  rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE are separate passes (TCC slots)."""
     def per_kernel(d, counter):
-        agg = defaultdict(lambda: [0, 0.0])
+        rows = []
         for f in find(d, "*counter_collection.csv"):
-            for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] != counter:
-                    continue
-                a = agg[short(r["Kernel_Name"])]
-                a[0] += 1; a[1] += float(r["Counter_Value"])
-        return {k: v[1] / v[0] for k, v in agg.items() if v[0]}
+            rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        ends = [i for i, r in enumerate(rows) if "icp_finish_kernel" in r["Kernel_Name"]]
+        seg = rows[ends[-nsteps - 1] + 1: ends[-1] + 1] if len(ends) > nsteps else rows
+        agg = defaultdict(lambda: [0, 0.0])
+        for r in seg:
+            a = agg[f'{short(r["Kernel_Name"])} [grid {r["Grid_Size"]}, wg {r["Workgroup_Size"]}]']
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+        return {k: (v[1] / v[0], v[0] / nsteps) for k, v in agg.items() if v[0]}
     fetch = per_kernel(fd, "FETCH_SIZE")
     write = per_kernel(wd, "WRITE_SIZE")
     res = {}
     for k in sorted(set(fetch) | set(write)):
-        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        f, nf = fetch.get(k, (0.0, 0)); w, _ = write.get(k, (0.0, 0))
         # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of
         # the bytes of a wide coalesced streaming read → doubled; WRITE_SIZE is exact for 16-B/lane streaming stores.
-        res[k] = dict(fetch_kib_raw=f, write_kib_raw=w, hbm_bytes_per_launch=(2.0 * f + w) * 1024.0,
-                      note="read side = 2 x FETCH_SIZE (gfx950 correction), calibrated for wide coalesced streams only")
+        res[k] = dict(launches_per_step=nf, fetch_kib_raw=round(f, 1), write_kib_raw=round(w, 1), hbm_bytes_per_launch=round((2.0 * f + w) * 1024.0),
+                      note="read side = 2 x FETCH_SIZE (gfx950 correction, calibrated for wide coalesced streams only); Infinity-Cache hits are counted")
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps(res, indent=1)[:3000])
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:20]:
+        print(f"{k:70s} {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB/launch  x{v['launches_per_step']:.1f}")
 
 
 if __name__ == "__main__":
@@ -101,4 +107,4 @@ if __name__ == "__main__":
     elif sys.argv[1] == "steady":
         steady(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 3)
