@@ -225,7 +225,7 @@ enum {
     LVI_DBG_VOXEL_COUNTS   = 8,   /* i32[V]   points per output voxel, same call */
     LVI_DBG_ICP_JTJ        = 9,   /* f32[iters*27] 21 upper-triangular AtA + 6 AtB per iteration */
     LVI_DBG_ICP_POSE_TRACE = 10,  /* f32[(iters+1)*6] transformTobeMapped before iteration k (and after the last) */
-    LVI_DBG_ICP_CYCLES     = 12,  /* i64[8] [hip only] shader cycles of workgroup 0 of the last residual launch: pose load, KNN scan,
+    LVI_DBG_ICP_CYCLES     = 12,  /* i64[16] [hip only] ([8..12]: solve kernel: partial sums, combine, solve, pose, total) shader cycles of workgroup 0 of the last residual launch: pose load, KNN scan,
                                      top-5 merge, residual math, row reduction, total; [6] = candidates scanned by lane 0 */
     LVI_DBG_FEAT_CYCLES    = 11   /* i64[8] [hip only] shader cycles of ring 0's sector kernel by phase: load, compact, rank, walk,
                                      fixed-point set-up, fixed-point rounds, number of rounds, apply+store */

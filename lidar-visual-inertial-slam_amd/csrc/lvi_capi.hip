@@ -567,7 +567,7 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
             case LVI_DBG_ICP_CYCLES: {
-                std::vector<long long> v(8); d2h(d, v.data(), d.d_icp_cycles, 8); sync(d);
+                std::vector<long long> v(16); d2h(d, v.data(), d.d_icp_cycles, 16); sync(d);
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
             case LVI_DBG_FEAT_CYCLES: {

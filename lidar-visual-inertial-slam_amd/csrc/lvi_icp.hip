@@ -147,25 +147,25 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         cell_of(m, qx, qy, qz, c);
         const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, m.dim[0] - 1);
         // memory-level parallelism is everything here (the index is L2-resident, ~300-700 cycles per dependent
-        // access): first all 18 row bounds, then the first two candidates of every row, in flight together
-        int rb[9], re[9];
+        // access): first all 18 row bounds in flight together, then the candidates in batches of KNN_KB per lane
+        int off[9], st[10];
+        st[0] = 0;
 #pragma unroll
         for (int q = 0; q < 9; q++) {
             const int z = c[2] + q / 3 - 1, y = c[1] + q % 3 - 1;
             const bool ok = x0 <= x1 && z >= 0 && z < m.dim[2] && y >= 0 && y < m.dim[1];
             const int row = ok ? (z * m.dim[1] + y) * m.dim[0] : 0;
-            rb[q] = ok ? cell_start[row + x0] : 0;
-            re[q] = ok ? cell_start[row + x1 + 1] : 0;
+            const int rb = ok ? cell_start[row + x0] : 0;
+            const int re = ok ? cell_start[row + x1 + 1] : 0;
+            off[q] = rb; st[q + 1] = re - rb;
         }
-        LVI_KT(1);
-        lvi_pt p0[9], p1[9];
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const int j0 = rb[q] + sub, j1 = j0 + KNN_G;
-            if (j0 < re[q]) p0[q] = sorted[j0];
-            if (j1 < re[q]) p1[q] = sorted[j1];
-        }
-        LVI_KT(2);
+        for (int q = 0; q < 9; q++) { const int len = st[q + 1]; st[q + 1] = st[q] + len; off[q] -= st[q]; }
+        const int T = st[9];
+        LVI_KT(1);
+        // The 9 rows (3 cells each, contiguous in the sorted array) form one flat candidate list of T entries;
+        // lane `sub` of the group takes entries sub, sub + G, …  (rows hold 0 to 30 points: a per-row split left
+        // lanes idle on short rows and in a serial tail of dependent loads on long ones).
         auto consider = [&](const lvi_pt& p) {
             const float ex = sub_rn(qx, p.x), ey = sub_rn(qy, p.y), ez = sub_rn(qz, p.z);
             const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
@@ -174,12 +174,20 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
             // candidates fall outside the unit ball and skip the insertion.
             if (dist < 1.0f) knn_insert(r, dist, __float_as_int(p.intensity));
         };
+        constexpr int KNN_KB = 8;
+        for (int f0 = sub; f0 < T; f0 += KNN_KB * KNN_G) {
+            lvi_pt p[KNN_KB];
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const int j0 = rb[q] + sub;
-            if (j0 < re[q]) consider(p0[q]);
-            if (j0 + KNN_G < re[q]) consider(p1[q]);
-            for (int j = j0 + 2 * KNN_G; j < re[q]; j += KNN_G) consider(sorted[j]);     // rows with more than 16 points
+            for (int u = 0; u < KNN_KB; u++) {
+                const int f = f0 + u * KNN_G;
+                int o = off[0];
+#pragma unroll
+                for (int q = 1; q < 9; q++) o = f >= st[q] ? off[q] : o;
+                if (f < T) p[u] = sorted[f + o];
+            }
+            LVI_KT(2);
+#pragma unroll
+            for (int u = 0; u < KNN_KB; u++) if (f0 + u * KNN_G < T) consider(p[u]);
         }
     }
     LVI_KT(3);
@@ -633,6 +641,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int
 {
     IcpState& s = *a.st;
     if (s.done) return;
+    const long long tq0 = clock64();
     __shared__ double part[SOLVE_THREADS / 32][28];
     __shared__ double sums[28];
     const int Q = a.nq[0] + a.nq[1];
@@ -641,11 +650,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int
         const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
         if (k < 28) {
             double v = 0.0;
-            for (int b = g; b < nb; b += SOLVE_THREADS / 32) v += a.partial[(size_t)b * 28 + k];
+            constexpr int GS = SOLVE_THREADS / 32;
+            for (int b0 = g; b0 < nb; b0 += 8 * GS) {                   // 8 loads in flight, summed in the fixed order b0, b0+GS, …
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int b = b0 + u * GS; t[u] = b < nb ? a.partial[(size_t)b * 28 + k] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) v += t[u];
+            }
             part[g][k] = v;
         }
     }
     __syncthreads();
+    const long long tq1 = clock64();
     if (threadIdx.x < 28) {
         double v = 0.0;
         for (int g = 0; g < SOLVE_THREADS / 32; g++) v += part[g][threadIdx.x];
@@ -653,6 +670,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
+    const long long tq2 = clock64();
     const int nsel = (int)sums[27];
     s.n_sel[iter] = nsel;
     s.iters = iter + 1;
@@ -702,7 +720,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int
             s.converged = 1;
             if (!a.disable_break) s.done = 1;
         }
+        const long long tq3 = clock64();
         make_pose(s.pose);
+        if (a.cyc && iter == 1) { const long long tq4 = clock64(); a.cyc[8] = tq1 - tq0; a.cyc[9] = tq2 - tq1; a.cyc[10] = tq3 - tq2; a.cyc[11] = tq4 - tq3; a.cyc[12] = tq4 - tq0; }
     }
 }
 

@@ -64,7 +64,7 @@ struct LidarDev {
     int* d_fresh = nullptr;                                // 1 until the first extract of this handle
     int* d_status = nullptr;
     long long* d_feat_cycles = nullptr;                    // [8] phase cycle counters of ring 0 (diagnostics)
-    long long* d_icp_cycles = nullptr;                     // [8] phase cycle counters of residual workgroup 0
+    long long* d_icp_cycles = nullptr;                     // [16] phase cycle counters: [0..7] residual workgroup 0, [8..15] solve kernel
     VoxelPlan voxRing;                                     // N_SCAN segments, leaf odometrySurfLeafSize
     // ---- scan DS
     lvi_pt *cornerDS = nullptr, *surfDS = nullptr;

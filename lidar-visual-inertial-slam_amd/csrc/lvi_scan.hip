@@ -516,7 +516,7 @@ void layout(AR& ar, LidarDev& d)
     d.corner = ar.template alloc<lvi_pt>(d.ext_cap); d.corner_idx = ar.template alloc<int>((size_t)NS * 6 * CORNERS_PER_SECTOR);
     d.d_ncorner = ar.template alloc<int>(1);
     d.surf = ar.template alloc<lvi_pt>(d.ext_cap);
-    d.d_fresh = ar.template alloc<int>(1); d.d_status = ar.template alloc<int>(1); d.d_feat_cycles = ar.template alloc<long long>(8); d.d_icp_cycles = ar.template alloc<long long>(8);
+    d.d_fresh = ar.template alloc<int>(1); d.d_status = ar.template alloc<int>(1); d.d_feat_cycles = ar.template alloc<long long>(8); d.d_icp_cycles = ar.template alloc<long long>(16);
     d.voxRing.allocate(ar, NS, d.ring_cap, true);
     d.cornerDS = ar.template alloc<lvi_pt>(d.ext_cap); d.surfDS = ar.template alloc<lvi_pt>(d.ext_cap);
     d.voxScan.allocate(ar, 2, d.ext_cap, false);

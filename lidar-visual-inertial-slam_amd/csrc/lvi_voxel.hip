@@ -407,9 +407,8 @@ __global__ __launch_bounds__(256) void vb_hist_kernel(VoxArgs a)
 {
     const int s = blockIdx.y;
     const int n = a.d_n[s];
-    const int base = blockIdx.x * VB_TILE;
     const VoxGrid& g = a.grid[s];
-    if (base >= n || g.nbins == 0) return;
+    if ((int)blockIdx.x * VB_TILE >= n || g.nbins == 0) return;
     __shared__ unsigned cnt[VB_NB];
     const int nbins = g.nbins, sh = g.bin_shift;
     for (int b = threadIdx.x; b < nbins; b += 256) cnt[b] = 0u;
@@ -417,13 +416,16 @@ __global__ __launch_bounds__(256) void vb_hist_kernel(VoxArgs a)
     const int off = a.dyn[s].in_off;
     const lvi_pt* __restrict__ in = a.st[s].in + off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+    // grid-stride over the tiles: one LDS histogram and one flush per workgroup, however many tiles it takes
+    for (int base = blockIdx.x * VB_TILE; base < n; base += gridDim.x * VB_TILE) {
 #pragma unroll 4
-    for (int u = 0; u < VB_TILE / 256; u++) {
-        const int i = base + u * 256 + threadIdx.x;
-        const bool ok = i < n && (!mask || mask[i]);
-        const unsigned bin = ok ? vox_key_of_pt(g, in[i]) >> sh : 0xFFFFFFFFu;
-        const WaveRun r = wave_runs(bin);
-        if (ok && r.head) atomicAdd(&cnt[bin], (unsigned)r.len);
+        for (int u = 0; u < VB_TILE / 256; u++) {
+            const int i = base + u * 256 + threadIdx.x;
+            const bool ok = i < n && (!mask || mask[i]);
+            const unsigned bin = ok ? vox_key_of_pt(g, in[i]) >> sh : 0xFFFFFFFFu;
+            const WaveRun r = wave_runs(bin);
+            if (ok && r.head) atomicAdd(&cnt[bin], (unsigned)r.len);
+        }
     }
     __syncthreads();
     unsigned* gc = a.binCount + (size_t)s * VB_NB;
@@ -819,7 +821,8 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag,
     if (mode == VOX_BINNED) {
         const dim3 gt(div_up(p.seg_cap, VB_TILE), p.nseg);
         const dim3 gb(std::min(VB_ACC_BLOCKS, VB_NB), p.nseg);
-        LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gt, dim3(256), 0, ctx.stream, a));
+        const dim3 gh2(std::min(div_up(p.seg_cap, VB_TILE), 512), p.nseg);
+        LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, a));
         LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg), dim3(256), 0, ctx.stream, a));
         LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, a));
         const dim3 ga(std::max(128, std::min(2 * div_up(p.seg_cap, VB_CH), 2048)), p.nseg);      // grid-stride over the chunks

@@ -15,5 +15,6 @@ print(L.counts())
 for rep in range(2):
     r = L.scan_match(S.perturbed_guess(pose, 0))
     c = L.debug_get(pkg._abi.DBG_ICP_CYCLES, np.int64)
-    names = ["pose+transform", "knn", "knn_inserts", "math", "reduce", "total", "knn_bounds", "knn_cand_loads"]
+    names = ["pose+transform", "knn", "knn_last_batch", "math", "reduce", "total", "knn_bounds", "knn_batches",
+             "solve:partials", "solve:combine", "solve:qr", "solve:pose", "solve:total"]
     print(r["iters"], {n: int(v) for n, v in zip(names, c) if n != "-"})

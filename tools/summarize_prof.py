@@ -63,9 +63,18 @@ def steady(d, out, nsteps):
         k = f'{short(r["Kernel_Name"])} [grid {r["Grid_Size_X"]}x{r["Grid_Size_Y"]}, wg {r["Workgroup_Size_X"]}]'
         a = agg[k]; a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
     total = sum(v[1] for v in agg.values())
+    # union of the kernel intervals = time with at least one kernel resident (the rest is launch gaps / idle)
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg)
+    union, cs, ce = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > ce:
+            union += ce - cs; cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    union += ce - cs
     with open(out, "w") as fo:
-        fo.write(f"steady state: last {nsteps} steps, wall {1e-3 * (t1 - t0) / nsteps:.1f} us/step, kernel-busy sum {total / nsteps:.1f} us/step "
-                 f"(two streams overlap)\n\n")
+        fo.write(f"steady state: last {nsteps} steps, wall {1e-3 * (t1 - t0) / nsteps:.1f} us/step, kernel-busy sum {total / nsteps:.1f} us/step, "
+                 f"at least one kernel resident {1e-3 * union / nsteps:.1f} us/step (streams overlap), {len(seg) / nsteps:.0f} launches/step\n\n")
         fo.write("| kernel [launch geometry] | calls/step | avg us | min us | max us | us/step | % of kernel time |\n|---|---:|---:|---:|---:|---:|---:|\n")
         for k, (n, t, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             fo.write(f"| {k} | {n / nsteps:.1f} | {t / n:.2f} | {mn:.2f} | {mx:.2f} | {t / nsteps:.1f} | {100 * t / total:.1f} |\n")
