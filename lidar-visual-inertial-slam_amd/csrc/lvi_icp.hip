@@ -6,10 +6,12 @@
 //   finish      transformUpdate (:1345-1375)
 //
 // Exact 5-NN without a kd-tree: both callers discard a query unless its 5th neighbour is closer
-// than 1 m (sqDis[4] < 1.0, :1025,1121).  The DS map is binned into a uniform grid of >= 1 m cells
-// (cell ids computed in double so that floor() is exact); every map point with squared distance
-// < 1 to a query lies in the 3x3x3 block of cells around it, so scanning that block yields exactly
-// FLANN's answer for every query the reference accepts, and "fewer than 5 within 1 m" for the rest.
+// than 1 m (sqDis[4] < 1.0, :1025,1121).  The DS map is binned into a uniform grid of 0.5 m cells
+// (1 m or more when 0.5 m would need more than max_cells; cell ids computed in double so that
+// floor() is exact); every map point with squared distance < 1 to a query lies in the 5x5x5 (3x3x3)
+// block of cells around it, and inside the block only in the cells the unit ball reaches, so scanning
+// those yields exactly FLANN's answer for every query the reference accepts, and "fewer than 5 within
+// 1 m" for the rest.
 // Distances are ((dx*dx)+dy*dy)+dz*dz in f32 without FMA, as FLANN's L2_Simple computes them.
 //
 // The Gauss-Newton loop never returns to the host: the 27 sums of AtA/AtB are reduced in double
@@ -52,25 +54,27 @@ __global__ void grid_meta_kernel(GridArgs a)
         lo[d] = mn - 1.0;                       // one cell of padding on every side
         ext[d] = mx - mn + 3.0;
     }
-    int c = 1;                                  // cell edge in metres, integer >= 1
+    int c = 1;                                  // cell edge in half metres, integer >= 1
     for (;; c++) {
-        const double nx = ceil(ext[0] / c), ny = ceil(ext[1] / c), nz = ceil(ext[2] / c);
+        const double e = 0.5 * c;
+        const double nx = ceil(ext[0] / e), ny = ceil(ext[1] / e), nz = ceil(ext[2] / e);
         if (nx * ny * nz <= (double)a.max_cells) { m.dim[0] = (int)nx; m.dim[1] = (int)ny; m.dim[2] = (int)nz; break; }
         if (c > 1 << 20) { atomicOr(a.d_status, DEV_ERR_GRID_TOO_LARGE); return; }
     }
-    // the cell edge is folded into the origin/scale: cell = floor((p - lo) / c)
+    // cell = floor((p - lo) / edge); a neighbour within 1 m is at most R cells away on every axis
     m.origin[0] = lo[0]; m.origin[1] = lo[1]; m.origin[2] = lo[2];
     m.ncells = m.dim[0] * m.dim[1] * m.dim[2];
-    m.ok = c;                                   // ok holds the cell edge (>= 1)
+    m.edge = 0.5 * c; m.inv_edge = 1.0 / m.edge; m.R = c == 1 ? 2 : 1;
+    m.ok = 1;
     a.d_nbits[w] = (m.ncells <= 1) ? 0 : (32 - __clz((unsigned)(m.ncells - 1)));
 }
 
 __device__ __forceinline__ void cell_of(const GridIndex::Meta& m, float x, float y, float z, int c[3])
 {
-    const double e = (double)m.ok;
-    c[0] = (int)floor(((double)x - m.origin[0]) / e);
-    c[1] = (int)floor(((double)y - m.origin[1]) / e);
-    c[2] = (int)floor(((double)z - m.origin[2]) / e);
+    // the same expression places the map points (grid_keys) and the queries (knn5_search_group)
+    c[0] = (int)floor(((double)x - m.origin[0]) * m.inv_edge);
+    c[1] = (int)floor(((double)y - m.origin[1]) * m.inv_edge);
+    c[2] = (int)floor(((double)z - m.origin[2]) * m.inv_edge);
 }
 
 __global__ __launch_bounds__(256) void grid_keys_kernel(GridArgs a)
@@ -117,94 +121,114 @@ __global__ __launch_bounds__(256) void grid_gather_kernel(GridArgs a)
 // ------------------------------------------------------------------------------------------- 5-NN
 struct Knn5 { float d[5]; int i[5]; };
 
-__device__ __forceinline__ void knn_insert(Knn5& r, float dist, int idx)
+// Private top-5 of a lane, ascending by (distance, index) as ONE 64-bit key per entry: squared distances are
+// >= 0, so their IEEE bit patterns order like unsigned integers; the index breaks exact ties.
+struct KnnKeys { unsigned long long k[5]; };
+constexpr unsigned long long KNN_EMPTY = 0x7F8000007FFFFFFFull;          // (+inf, INT_MAX)
+__device__ __forceinline__ unsigned long long knn_key(float dist, int idx) { return ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)idx; }
+__device__ __forceinline__ void knn_insert(KnnKeys& r, unsigned long long key)
 {
-    // ascending by (distance, index)
-    if (!(dist < r.d[4] || (dist == r.d[4] && idx < r.i[4]))) return;
-    r.d[4] = dist; r.i[4] = idx;
-#pragma unroll
-    for (int k = 4; k > 0; k--) {
-        const bool sw = (r.d[k] < r.d[k - 1]) || (r.d[k] == r.d[k - 1] && r.i[k] < r.i[k - 1]);
-        if (sw) { const float td = r.d[k]; r.d[k] = r.d[k - 1]; r.d[k - 1] = td; const int ti = r.i[k]; r.i[k] = r.i[k - 1]; r.i[k - 1] = ti; }
-    }
+    // branch-free insertion into the sorted list: entry j becomes min(max(old[j-1], key), old[j])
+    const unsigned long long o0 = r.k[0], o1 = r.k[1], o2 = r.k[2], o3 = r.k[3], o4 = r.k[4];
+    r.k[0] = key < o0 ? key : o0;
+    r.k[1] = key < o0 ? o0 : (key < o1 ? key : o1);
+    r.k[2] = key < o1 ? o1 : (key < o2 ? key : o2);
+    r.k[3] = key < o2 ? o2 : (key < o3 ? key : o3);
+    r.k[4] = key < o3 ? o3 : (key < o4 ? key : o4);
 }
 
-// G (=8) consecutive lanes share one query: every lane scans a strided share of the candidate rows
-// (adjacent lanes read adjacent 16-B points → coalesced), keeps a private top-5, then the G lists are
-// merged by 5 rounds of a group-wide (distance, index) minimum.  All G lanes end with the same result.
+// G (=8) consecutive lanes share one query.  The block of cells around the query is (2R+1)^2 rows along x
+// (R = 2 for 0.5 m cells); lane `sub` owns rows sub, sub + G, … .  A row is skipped when its (y, z) slab is a
+// metre or more away, and its x-range is cut to the cells the unit ball reaches in that slab, so the lanes
+// scan ~2.3x the ball's volume instead of the 27 m^3 of a 3x3x3 block of 1 m cells.  The cells of a row
+// are contiguous in the cell-sorted array: 2 bound loads per row (all in flight together), then the lane's
+// rows form one flat candidate list read in batches of KNN_KB (adjacent lanes read different rows, the index
+// is L2-resident).  Each lane keeps a private top-5; the G lists are merged by 5 rounds of a group-wide
+// (distance, index) minimum.  All G lanes end with the same result.
 constexpr int KNN_G = 8;
+constexpr int KNN_RPL = 4;                // rows per lane: ceil(25 / KNN_G)
 
 __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
                                                   float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr)
 {
 #define LVI_KT(slot) do { if (tk) tk[slot] = clock64(); } while (0)
     LVI_KT(0);
-    Knn5 r;
+    KnnKeys r;
 #pragma unroll
-    for (int k = 0; k < 5; k++) { r.d[k] = INFINITY; r.i[k] = 0x7fffffff; }
+    for (int k = 0; k < 5; k++) r.k[k] = KNN_EMPTY;
     if (m.ok && m.n > 0) {
-        int c[3];
-        cell_of(m, qx, qy, qz, c);
-        const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, m.dim[0] - 1);
-        // memory-level parallelism is everything here (the index is L2-resident, ~300-700 cycles per dependent
-        // access): first all 18 row bounds in flight together, then the candidates in batches of KNN_KB per lane
-        int off[9], st[10];
+        const float e = (float)m.edge, inv_e = (float)m.inv_edge;
+        const int R = m.R, W = 2 * R + 1, nrows = W * W;
+        // cell of the query (double, as cell_of) and its position inside that cell in [0,1) (f32 is plenty: the row
+        // tests below only have to be conservative, and they carry a 1e-4 margin)
+        const double gx = ((double)qx - m.origin[0]) * m.inv_edge, gy = ((double)qy - m.origin[1]) * m.inv_edge, gz = ((double)qz - m.origin[2]) * m.inv_edge;
+        const double fxd = floor(gx), fyd = floor(gy), fzd = floor(gz);
+        const float tx = (float)(gx - fxd), ty = (float)(gy - fyd), tz = (float)(gz - fzd);
+        // far outside the grid nothing can be within 1 m (2 cells of padding): clamp so that the ints below cannot overflow
+        const int cx = (int)fmin(fmax(fxd, -4.0), (double)m.dim[0] + 4.0), cy = (int)fmin(fmax(fyd, -4.0), (double)m.dim[1] + 4.0),
+                  cz = (int)fmin(fmax(fzd, -4.0), (double)m.dim[2] + 4.0);
+        int off[KNN_RPL], st[KNN_RPL + 1];
         st[0] = 0;
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const int z = c[2] + q / 3 - 1, y = c[1] + q % 3 - 1;
-            const bool ok = x0 <= x1 && z >= 0 && z < m.dim[2] && y >= 0 && y < m.dim[1];
-            const int row = ok ? (z * m.dim[1] + y) * m.dim[0] : 0;
-            const int rb = ok ? cell_start[row + x0] : 0;
-            const int re = ok ? cell_start[row + x1 + 1] : 0;
-            off[q] = rb; st[q + 1] = re - rb;
+        for (int t = 0; t < KNN_RPL; t++) {
+            const int rr = sub + KNN_G * t;
+            int rb = 0, len = 0;
+            const int dy = rr % W - R, dz = rr / W - R;
+            const int y = cy + dy, z = cz + dz;
+            if (rr < nrows && y >= 0 && y < m.dim[1] && z >= 0 && z < m.dim[2]) {
+                // distance (m) from the query to the row's slab along y and z; 0 inside
+                const float ddy = dy == 0 ? 0.f : (dy > 0 ? (float)dy - ty : ty - (float)(dy + 1)) * e;
+                const float ddz = dz == 0 ? 0.f : (dz > 0 ? (float)dz - tz : tz - (float)(dz + 1)) * e;
+                // margins: the f32 distance of a candidate may round below 1 when the exact one is just above
+                const float rem = 1.0f + 1e-4f - ddy * ddy - ddz * ddz;
+                if (rem > 0.f) {
+                    const float sx = sqrtf(rem) * inv_e + 1e-4f;
+                    const int x0 = max(cx + (int)floorf(tx - sx), 0), x1 = min(cx + (int)floorf(tx + sx), m.dim[0] - 1);
+                    if (x0 <= x1) {
+                        const int row = (z * m.dim[1] + y) * m.dim[0];
+                        rb = cell_start[row + x0];
+                        len = cell_start[row + x1 + 1] - rb;
+                    }
+                }
+            }
+            off[t] = rb; st[t + 1] = len;
         }
 #pragma unroll
-        for (int q = 0; q < 9; q++) { const int len = st[q + 1]; st[q + 1] = st[q] + len; off[q] -= st[q]; }
-        const int T = st[9];
+        for (int t = 0; t < KNN_RPL; t++) { const int len = st[t + 1]; st[t + 1] = st[t] + len; off[t] -= st[t]; }
+        const int T = st[KNN_RPL];
         LVI_KT(1);
-        // The 9 rows (3 cells each, contiguous in the sorted array) form one flat candidate list of T entries;
-        // lane `sub` of the group takes entries sub, sub + G, …  (rows hold 0 to 30 points: a per-row split left
-        // lanes idle on short rows and in a serial tail of dependent loads on long ones).
-        auto consider = [&](const lvi_pt& p) {
-            const float ex = sub_rn(qx, p.x), ey = sub_rn(qy, p.y), ez = sub_rn(qz, p.z);
-            const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
-            // Only neighbours closer than 1 m can matter: the callers reject a feature unless its 5th neighbour has
-            // sqDis < 1.0, and if five such neighbours exist they ARE the five nearest.  ~3/4 of the 27-cell
-            // candidates fall outside the unit ball and skip the insertion.
-            if (dist < 1.0f) knn_insert(r, dist, __float_as_int(p.intensity));
-        };
         constexpr int KNN_KB = 8;
-        for (int f0 = sub; f0 < T; f0 += KNN_KB * KNN_G) {
+        for (int f0 = 0; f0 < T; f0 += KNN_KB) {
             lvi_pt p[KNN_KB];
 #pragma unroll
             for (int u = 0; u < KNN_KB; u++) {
-                const int f = f0 + u * KNN_G;
+                const int f = f0 + u;
                 int o = off[0];
 #pragma unroll
-                for (int q = 1; q < 9; q++) o = f >= st[q] ? off[q] : o;
+                for (int t = 1; t < KNN_RPL; t++) o = f >= st[t] ? off[t] : o;
                 if (f < T) p[u] = sorted[f + o];
             }
             LVI_KT(2);
 #pragma unroll
-            for (int u = 0; u < KNN_KB; u++) if (f0 + u * KNN_G < T) consider(p[u]);
+            for (int u = 0; u < KNN_KB; u++) {
+                const float ex = sub_rn(qx, p[u].x), ey = sub_rn(qy, p[u].y), ez = sub_rn(qz, p[u].z);
+                const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+                // Only neighbours closer than 1 m can matter: the callers reject a feature unless its 5th neighbour has
+                // sqDis < 1.0, and if five such neighbours exist they ARE the five nearest.
+                const bool take = f0 + u < T && dist < 1.0f;
+                knn_insert(r, take ? knn_key(dist, __float_as_int(p[u].intensity)) : KNN_EMPTY);
+            }
         }
     }
     LVI_KT(3);
+    // merge: 5 rounds of a group-wide minimum; the owner of the winner pops it (keys are unique per lane)
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        float hd = r.d[0]; int hi = r.i[0];
+        unsigned long long h = r.k[0];
 #pragma unroll
-        for (int o = KNN_G / 2; o > 0; o >>= 1) {
-            const float od = __shfl_xor(hd, o, 64); const int oi = __shfl_xor(hi, o, 64);
-            if (od < hd || (od == hd && oi < hi)) { hd = od; hi = oi; }
-        }
-        out.d[k] = hd; out.i[k] = hi;
-        if (r.d[0] == hd && r.i[0] == hi) {           // the owner of the winner pops it (indices are unique per lane)
-#pragma unroll
-            for (int q = 0; q < 4; q++) { r.d[q] = r.d[q + 1]; r.i[q] = r.i[q + 1]; }
-            r.d[4] = INFINITY; r.i[4] = 0x7fffffff;
-        }
+        for (int o = KNN_G / 2; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(h, o, 64); h = v < h ? v : h; }
+        out.d[k] = __uint_as_float((unsigned)(h >> 32)); out.i[k] = (int)(unsigned)h;
+        if (r.k[0] == h && h != KNN_EMPTY) { r.k[0] = r.k[1]; r.k[1] = r.k[2]; r.k[2] = r.k[3]; r.k[3] = r.k[4]; r.k[4] = KNN_EMPTY; }
     }
 }
 
@@ -447,15 +471,15 @@ __device__ __forceinline__ void lm_row(const float tr[6], const lvi_pt& ori, con
     rowB = -cf.intensity;
 }
 
-constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup (32)
+constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup (64: the residual phase fills its wavefront)
 static_assert(ICP_QPB <= 64, "the residual phase runs on one wavefront");
 
-// Two phases per workgroup of 32 features:
-//   A  all 256 threads: transform + 5-NN, 8 lanes per feature; the merged neighbour lists go to LDS
+// Two phases per workgroup of 64 features:
+//   A  all 512 threads: transform + 5-NN, 8 lanes per feature; the merged neighbour lists go to LDS
 //   B  ONE wavefront, one lane per feature: line / plane fit, residual, Gauss-Newton row (6+1 values) and its
 //      27 products in f64, into LDS; then 28 threads add the 32 rows in fixed order → one partial per workgroup.
 // (Doing B inside the 8-lane groups made every wavefront execute the whole eigen/QR code for 8 active lanes;
-// 512-thread workgroups with 16 lanes per feature were measured slower: only one fits per CU at this VGPR count.)
+// the kernel is VALU-issue bound, ~2500 instructions per lane, not latency bound: half-filled wavefronts in B cost.)
 __global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
 {
     if (a.st->done) return;

@@ -9,7 +9,7 @@ constexpr int ORG_TILE = 1024;          // raw points per workgroup in the organ
 constexpr int FEAT_SEG_CAP = 8192;      // max points of one ring sector held in LDS (+ halo)
 constexpr int MAX_N_SCAN = 32;
 constexpr int CORNERS_PER_SECTOR = 40;  // featureExtraction.cpp:180
-constexpr int ICP_BLOCK = 256;          // residual workgroup: 32 features x 8 lanes
+constexpr int ICP_BLOCK = 512;          // residual workgroup: 64 features x 8 lanes
 
 // device status bits (sticky until the next upload)
 enum { DEV_ERR_SECTOR_TOO_LARGE = 1, DEV_ERR_GRID_TOO_LARGE = 2 };
@@ -31,10 +31,10 @@ struct IcpState {                        // device, one per handle
     float final_pose[6];
 };
 
-struct GridIndex {                       // uniform 1 m grid over one DS map (a-6 replacement for the kd-tree)
+struct GridIndex {                       // uniform 0.5 m grid over one DS map (a-6 replacement for the kd-tree)
     int* cell_start = nullptr;           // [max_cells + 1]
     lvi_pt* sorted = nullptr;            // [cap] xyz + original DS index in the intensity slot (as int bits)
-    struct Meta { double origin[3]; int dim[3]; int ncells; int n; int ok; }* meta = nullptr;   // device
+    struct Meta { double origin[3]; double edge, inv_edge; int dim[3]; int ncells; int n; int ok; int R; }* meta = nullptr;   // device
 };
 
 struct LidarDev {
