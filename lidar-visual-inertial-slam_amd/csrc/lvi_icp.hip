@@ -32,8 +32,9 @@ struct GridArgs {
     const lvi_pt* ds[2];
     int* cell_start[2];
     lvi_pt* sorted[2];
-    unsigned *keysA, *valsA, *keysB, *valsB;
-    int *d_n, *d_nbits;
+    int* count[2];                 // [max_cells + 1] points per cell, zero between builds
+    int* cursor[2];                // [max_cells + 1] scatter cursors
+    int* blockSum[2];              // [GRID_SCAN_BLOCKS]
     int cap, max_cells;
     int* d_status;
 };
@@ -45,7 +46,6 @@ __global__ void grid_meta_kernel(GridArgs a)
     GridIndex::Meta& m = *a.meta[w];
     const int n = a.nout[w];
     m.n = n; m.ok = 0;
-    a.d_n[w] = n; a.d_nbits[w] = 0;
     m.dim[0] = m.dim[1] = m.dim[2] = 1; m.ncells = 1; m.origin[0] = m.origin[1] = m.origin[2] = 0.0;
     if (n <= 0 || a.vox[w].n_valid == 0) return;
     double lo[3], ext[3];
@@ -66,7 +66,6 @@ __global__ void grid_meta_kernel(GridArgs a)
     m.ncells = m.dim[0] * m.dim[1] * m.dim[2];
     m.edge = 0.5 * c; m.inv_edge = 1.0 / m.edge; m.R = c == 1 ? 2 : 1;
     m.ok = 1;
-    a.d_nbits[w] = (m.ncells <= 1) ? 0 : (32 - __clz((unsigned)(m.ncells - 1)));
 }
 
 __device__ __forceinline__ void cell_of(const GridIndex::Meta& m, float x, float y, float z, int c[3])
@@ -77,45 +76,85 @@ __device__ __forceinline__ void cell_of(const GridIndex::Meta& m, float x, float
     c[2] = (int)floor(((double)z - m.origin[2]) * m.inv_edge);
 }
 
-__global__ __launch_bounds__(256) void grid_keys_kernel(GridArgs a)
+__device__ __forceinline__ int cell_id_of(const GridIndex::Meta& m, const lvi_pt& p)
 {
-    const int w = blockIdx.y;
-    const GridIndex::Meta& m = *a.meta[w];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m.n || !m.ok) return;
-    const lvi_pt p = a.ds[w][i];
     int c[3];
     cell_of(m, p.x, p.y, p.z, c);
 #pragma unroll
     for (int d = 0; d < 3; d++) c[d] = min(max(c[d], 0), m.dim[d] - 1);
-    a.keysA[(size_t)w * a.cap + i] = (unsigned)((c[2] * m.dim[1] + c[1]) * m.dim[0] + c[0]);
-    a.valsA[(size_t)w * a.cap + i] = (unsigned)i;
+    return (c[2] * m.dim[1] + c[1]) * m.dim[0] + c[0];
 }
 
-// cell_start[c] = first sorted position whose cell id >= c (lower bound), for c in [0, ncells]
-__global__ __launch_bounds__(256) void grid_fill_kernel(GridArgs a)
+// The index is a counting sort by cell WITHOUT a stable order: the 5-NN result is a minimum over a total order
+// of (distance, index) keys, so the order of the points inside a cell cannot change it.  count → exclusive scan
+// (two kernels, GRID_SCAN_BLOCKS chunks) → scatter through per-cell cursors.  Every kernel is a grid-stride
+// loop over device-side counts: the launch geometry does not depend on the (device-only) map size.
+constexpr int GRID_PT_BLOCKS = 512;
+constexpr int GRID_SCAN_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void grid_count_kernel(GridArgs a)
 {
     const int w = blockIdx.y;
     const GridIndex::Meta& m = *a.meta[w];
-    const unsigned* keys = (rs_result_in_B(a.d_nbits[w]) ? a.keysB : a.keysA) + (size_t)w * a.cap;
-    for (int c = blockIdx.x * 256 + threadIdx.x; c <= m.ncells; c += gridDim.x * 256) {
-        int lo = 0, hi = m.ok ? m.n : 0;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < (unsigned)c) lo = mid + 1; else hi = mid; }
-        a.cell_start[w][c] = lo;
+    if (!m.ok) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m.n; i += gridDim.x * 256) atomicAdd(&a.count[w][cell_id_of(m, a.ds[w][i])], 1);
+}
+
+// chunk b of the ncells + 1 entries: its total
+__global__ __launch_bounds__(256) void grid_scan_sum_kernel(GridArgs a)
+{
+    const int w = blockIdx.y;
+    const GridIndex::Meta& m = *a.meta[w];
+    const int total = m.ncells + 1;
+    const int L = (total + GRID_SCAN_BLOCKS - 1) / GRID_SCAN_BLOCKS;
+    const int c0 = blockIdx.x * L, c1 = min(total, c0 + L);
+    int v = 0;
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) v += (c < m.ncells && m.ok) ? a.count[w][c] : 0;
+    __shared__ int ws[8];
+    int tot;
+    (void)block_excl_scan<256>(v, ws, &tot);
+    if (threadIdx.x == 0) a.blockSum[w][blockIdx.x] = tot;
+}
+
+// cell_start[c] = points in cells < c, for c in [0, ncells]; cursor = the same; count back to zero
+__global__ __launch_bounds__(256) void grid_scan_apply_kernel(GridArgs a)
+{
+    const int w = blockIdx.y;
+    const GridIndex::Meta& m = *a.meta[w];
+    const int total = m.ncells + 1;
+    const int L = (total + GRID_SCAN_BLOCKS - 1) / GRID_SCAN_BLOCKS;
+    const int c0 = blockIdx.x * L, c1 = min(total, c0 + L);
+    if (c0 >= c1) return;
+    __shared__ int ws[8];
+    int carry;
+    {
+        int v = 0;
+        for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) v += a.blockSum[w][j];
+        (void)block_excl_scan<256>(v, ws, &carry);
+    }
+    for (int base = c0; base < c1; base += 256) {
+        const int c = base + threadIdx.x;
+        const bool live = c < c1 && c < m.ncells && m.ok;
+        const int v = live ? a.count[w][c] : 0;
+        int tot;
+        const int ex = carry + block_excl_scan<256>(v, ws, &tot);
+        if (c < c1) { a.cell_start[w][c] = ex; a.cursor[w][c] = ex; }
+        if (live) a.count[w][c] = 0;
+        carry += tot;
     }
 }
 
-__global__ __launch_bounds__(256) void grid_gather_kernel(GridArgs a)
+__global__ __launch_bounds__(256) void grid_scatter_kernel(GridArgs a)
 {
     const int w = blockIdx.y;
     const GridIndex::Meta& m = *a.meta[w];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m.n || !m.ok) return;
-    const unsigned* vals = (rs_result_in_B(a.d_nbits[w]) ? a.valsB : a.valsA) + (size_t)w * a.cap;
-    const unsigned src = vals[i];
-    lvi_pt p = a.ds[w][src];
-    p.intensity = __int_as_float((int)src);     // original index in laserCloud*FromMapDS
-    a.sorted[w][i] = p;
+    if (!m.ok) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m.n; i += gridDim.x * 256) {
+        lvi_pt p = a.ds[w][i];
+        const int pos = atomicAdd(&a.cursor[w][cell_id_of(m, p)], 1);
+        p.intensity = __int_as_float(i);        // original index in laserCloud*FromMapDS
+        a.sorted[w][pos] = p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- 5-NN
@@ -890,18 +929,19 @@ void stage_map_build(LidarDev& d)
     voxel_downsample_batch(cx, d.voxMap, "map", n);
 
     GridArgs g{};
-    for (int w = 0; w < 2; w++) { g.meta[w] = d.grid[w].meta; g.cell_start[w] = d.grid[w].cell_start; g.sorted[w] = d.grid[w].sorted; }
+    for (int w = 0; w < 2; w++) {
+        g.meta[w] = d.grid[w].meta; g.cell_start[w] = d.grid[w].cell_start; g.sorted[w] = d.grid[w].sorted;
+        g.count[w] = d.grid[w].count; g.cursor[w] = d.grid[w].cursor; g.blockSum[w] = d.grid[w].blockSum;
+    }
     g.vox = d.voxMap.d_grid; g.nout = d.voxMap.d_nout;
     g.ds[0] = d.mapCornerDS; g.ds[1] = d.mapSurfDS;
-    g.keysA = d.gridSort.keysA; g.valsA = d.gridSort.valsA; g.keysB = d.gridSort.keysB; g.valsB = d.gridSort.valsB;
-    g.d_n = d.d_grid_n; g.d_nbits = d.d_grid_nbits; g.cap = d.map_cap; g.max_cells = d.max_cells; g.d_status = d.d_status;
-    const double nds = 0.2 * n;      // nominal DS size for byte accounting only
-    const dim3 gp(div_up(d.map_cap, 256), 2);
+    g.cap = d.map_cap; g.max_cells = d.max_cells; g.d_status = d.d_status;
+    const double nds = 0.02 * n;     // nominal DS size for byte accounting only
     LVI_LAUNCH(cx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1), dim3(64), 0, cx.stream, g));
-    LVI_LAUNCH(cx, "grid_keys", 24.0 * nds, hipLaunchKernelGGL(grid_keys_kernel, gp, dim3(256), 0, cx.stream, g));
-    radix_sort_pairs(cx, d.gridSort, d.d_grid_n, d.d_grid_nbits, 3, "grid", nds);
-    LVI_LAUNCH(cx, "grid_fill", 0, hipLaunchKernelGGL(grid_fill_kernel, dim3(2048, 2), dim3(256), 0, cx.stream, g));
-    LVI_LAUNCH(cx, "grid_gather", 36.0 * nds, hipLaunchKernelGGL(grid_gather_kernel, gp, dim3(256), 0, cx.stream, g));
+    LVI_LAUNCH(cx, "grid_count", 16.0 * nds, hipLaunchKernelGGL(grid_count_kernel, dim3(GRID_PT_BLOCKS, 2), dim3(256), 0, cx.stream, g));
+    LVI_LAUNCH(cx, "grid_scan_sum", 0, hipLaunchKernelGGL(grid_scan_sum_kernel, dim3(GRID_SCAN_BLOCKS, 2), dim3(256), 0, cx.stream, g));
+    LVI_LAUNCH(cx, "grid_scan_apply", 0, hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GRID_SCAN_BLOCKS, 2), dim3(256), 0, cx.stream, g));
+    LVI_LAUNCH(cx, "grid_scatter", 32.0 * nds, hipLaunchKernelGGL(grid_scatter_kernel, dim3(GRID_PT_BLOCKS, 2), dim3(256), 0, cx.stream, g));
     LVI_HIP(hipEventRecord(d.evMap, cx.stream));
     d.map_pending = true;
 }

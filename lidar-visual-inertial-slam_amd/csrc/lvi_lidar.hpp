@@ -32,7 +32,9 @@ struct IcpState {                        // device, one per handle
 };
 
 struct GridIndex {                       // uniform 0.5 m grid over one DS map (a-6 replacement for the kd-tree)
-    int* cell_start = nullptr;           // [max_cells + 1]
+    int* cell_start = nullptr;           // [max_cells + 2]
+    int *count = nullptr, *cursor = nullptr;   // [max_cells + 2] points per cell (zero between builds), scatter cursors
+    int* blockSum = nullptr;             // [1024] chunk totals of the cell scan
     lvi_pt* sorted = nullptr;            // [cap] xyz + original DS index in the intensity slot (as int bits)
     struct Meta { double origin[3]; double edge, inv_edge; int dim[3]; int ncells; int n; int ok; int R; }* meta = nullptr;   // device
 };
@@ -74,8 +76,7 @@ struct LidarDev {
     int n_map_corner = 0, n_map_surf = 0;
     VoxelPlan voxMap;                                      // 2 segments
     GridIndex grid[2];
-    SortPlan gridSort;                                     // 2 segments (corner, surf)
-    int *d_grid_n = nullptr, *d_grid_nbits = nullptr;
+
     // ---- generic one-call voxel (lvi_voxel_downsample)
     lvi_pt *genIn = nullptr, *genOut = nullptr;
     VoxelPlan voxGen;                                      // 1 segment

@@ -526,11 +526,12 @@ void layout(AR& ar, LidarDev& d)
     d.voxMap.centroid_lanes = 32;
     for (int w = 0; w < 2; w++) {
         d.grid[w].cell_start = ar.template alloc<int>((size_t)d.max_cells + 2);
+        d.grid[w].count = ar.template alloc<int>((size_t)d.max_cells + 2);
+        d.grid[w].cursor = ar.template alloc<int>((size_t)d.max_cells + 2);
+        d.grid[w].blockSum = ar.template alloc<int>(1024);
         d.grid[w].sorted = ar.template alloc<lvi_pt>(d.map_cap);
         d.grid[w].meta = ar.template alloc<GridIndex::Meta>(1);
     }
-    d.gridSort.allocate(ar, 2, d.map_cap);
-    d.d_grid_n = ar.template alloc<int>(2); d.d_grid_nbits = ar.template alloc<int>(2);
     const int gen_cap = std::max(d.raw_cap, d.map_cap);
     d.genIn = ar.template alloc<lvi_pt>(gen_cap); d.genOut = ar.template alloc<lvi_pt>(gen_cap);
     d.voxGen.allocate(ar, 1, gen_cap, false);
