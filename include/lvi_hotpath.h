@@ -110,6 +110,20 @@ typedef struct lvi_cloud {
     lvi_pt *pts;
 } lvi_cloud;
 
+/* The rotation table imuDeskewInfo() integrates from the IMU queue (imageProjection.cpp:354-410), as plain
+ * caller-owned arrays: the queue handling stays in the node, the per-point work (findRotation :495-520,
+ * deskewPoint :538-568) moves into lvi_scan_organize.  SURVEY §8 row f-1. */
+#define LVI_DESKEW_MAX_IMU 2000     /* queueLength, imageProjection.cpp:50 */
+typedef struct lvi_deskew_info {
+    int32_t imu_available;          /* cloudInfo.imu_available (:408); 0 = deskewPoint returns the point */
+    int32_t imu_pointer_cur;        /* imuPointerCur after :404 = last valid table index, >= 1 when available */
+    double  time_scan_cur;          /* timeScanCur (:283), seconds */
+    const double *imu_time;         /* [imu_pointer_cur + 1]  imuTime[] */
+    const double *imu_rot_x;        /* [imu_pointer_cur + 1]  imuRotX[] … */
+    const double *imu_rot_y;
+    const double *imu_rot_z;
+} lvi_deskew_info;
+
 /* CloudInfo fields consumed by transformUpdate (mapOptimization.cpp:1345-1368) */
 typedef struct lvi_imu_hint {
     int32_t imu_available;
@@ -153,6 +167,8 @@ int32_t lvi_lidar_sync(lvi_lidar *h);                       /* wait for the hand
  *      (imageProjection.cpp:239-260, 570-647), imu_available == false (no deskew).
  *      n_raw = Msg.point_num; the final point is dropped as the reference does (:249). */
 int32_t lvi_organize_scan(lvi_lidar *h, const lvi_livox_pt *pts, int32_t n_raw, lvi_scan_info *out);
+/* the same with per-point IMU deskew: projectPointCloud's deskewPoint call (imageProjection.cpp:614) */
+int32_t lvi_organize_scan_deskew(lvi_lidar *h, const lvi_livox_pt *pts, int32_t n_raw, const lvi_deskew_info *info, lvi_scan_info *out);
 
 /* a-1..a-4  FeatureExtraction::laserCloudInfoHandler (featureExtraction.cpp:72-85):
  *      calculateSmoothness, markOccludedPoints, extractFeatures (incl. per-ring VoxelGrid). */
@@ -181,7 +197,9 @@ int32_t lvi_transform_cloud(lvi_lidar *h, const lvi_pt *in, int32_t n, const flo
  * upload → run stages on the handle's stream → fetch.  Used by the replay
  * harness and bench so that inputs are resident in HBM when timing starts. */
 int32_t lvi_scan_upload(lvi_lidar *h, const lvi_livox_pt *pts, int32_t n_raw);   /* H2D only */
-int32_t lvi_scan_organize(lvi_lidar *h);                                         /* a-0 */
+int32_t lvi_scan_organize(lvi_lidar *h);                                         /* a-0 (+ f-1 when a deskew table is set) */
+/* f-1: rotation table for the NEXT lvi_scan_organize calls (copied; NULL or imu_available == 0 switches deskew off). */
+int32_t lvi_scan_set_deskew(lvi_lidar *h, const lvi_deskew_info *info);
 int32_t lvi_scan_extract(lvi_lidar *h);                                          /* a-1..a-4 */
 int32_t lvi_scan_downsample(lvi_lidar *h);                                       /* downsampleCurrentScan :987-999 */
 int32_t lvi_map_upload(lvi_lidar *h, const lvi_pt *corner_raw, int32_t nc, const lvi_pt *surf_raw, int32_t ns);

@@ -54,6 +54,12 @@ class ScanInfo(C.Structure):
                 ("cloud_deskewed", C.c_void_p)]
 
 
+class DeskewInfo(C.Structure):
+    _fields_ = [("imu_available", C.c_int32), ("imu_pointer_cur", C.c_int32), ("time_scan_cur", C.c_double),
+                ("imu_time", C.POINTER(C.c_double)), ("imu_rot_x", C.POINTER(C.c_double)),
+                ("imu_rot_y", C.POINTER(C.c_double)), ("imu_rot_z", C.POINTER(C.c_double))]
+
+
 class Cloud(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("n", C.c_int32), ("pts", C.c_void_p)]
 
@@ -99,6 +105,8 @@ SIGNATURES = {
     "lvi_transform_cloud": (_i32, [_vp, _vp, _i32, _P(_f32), _vp]),
     "lvi_scan_upload": (_i32, [_vp, _vp, _i32]),
     "lvi_scan_organize": (_i32, [_vp]),
+    "lvi_scan_set_deskew": (_i32, [_vp, _vp]),
+    "lvi_organize_scan_deskew": (_i32, [_vp, _vp, _i32, _vp, _P(ScanInfo)]),
     "lvi_scan_extract": (_i32, [_vp]),
     "lvi_scan_downsample": (_i32, [_vp]),
     "lvi_map_upload": (_i32, [_vp, _vp, _i32, _vp, _i32]),

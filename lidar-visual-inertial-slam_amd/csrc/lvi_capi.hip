@@ -345,8 +345,8 @@ int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, 
             stage_downsample(d); d.have_ds = true;
             stage_scan_match_enqueue(d, nullptr, nullptr);
         };
-        if (d.prof.on) {
-            run_stages();                                         // per-kernel HIP events need eager launches
+        if (d.prof.on || d.dk_on) {
+            run_stages();                                         // per-kernel HIP events need eager launches; the deskew table's time origin is a kernel argument
         } else {
             const bool stale = !d.graphExec || d.graph_n_raw != d.n_raw || d.graph_nc != d.n_map_corner || d.graph_ns != d.n_map_surf ||
                                d.graph_rebuild != (rebuild_map ? 1 : 0);
@@ -442,9 +442,36 @@ int32_t lvi_get_pose_record(lvi_lidar* h, lvi_pose_record* out)
 }
 
 // ---- one-call forms ------------------------------------------------------------------------------
+int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    h->d.dk_on = false;
+    if (!info || !info->imu_available) return LVI_OK;
+    if (info->imu_pointer_cur < 1 || info->imu_pointer_cur >= LVI_DESKEW_MAX_IMU || !info->imu_time || !info->imu_rot_x || !info->imu_rot_y || !info->imu_rot_z)
+        return fail(LVI_ERR_INVALID_ARG, "bad deskew table");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        const size_t m = (size_t)info->imu_pointer_cur + 1;
+        const double* src[4] = {info->imu_time, info->imu_rot_x, info->imu_rot_y, info->imu_rot_z};
+        for (int k = 0; k < 4; k++) h2d(d, d.d_dk + (size_t)k * LVI_DESKEW_MAX_IMU, src[k], m);
+        sync(d);                                            // the caller's arrays may go away after the call
+        d.dk_cur = info->imu_pointer_cur; d.dk_t0 = info->time_scan_cur; d.dk_on = true;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_organize_scan_deskew(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw, const lvi_deskew_info* info, lvi_scan_info* out)
+{
+    int32_t st = lvi_scan_set_deskew(h, info); if (st) return st;
+    st = lvi_scan_upload(h, pts, n_raw); if (st) return st;
+    st = lvi_scan_organize(h); if (st) return st;
+    return lvi_get_scan_info(h, out);
+}
+
 int32_t lvi_organize_scan(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw, lvi_scan_info* out)
 {
-    int32_t st = lvi_scan_upload(h, pts, n_raw); if (st) return st;
+    int32_t st = lvi_scan_set_deskew(h, nullptr); if (st) return st;
+    st = lvi_scan_upload(h, pts, n_raw); if (st) return st;
     st = lvi_scan_organize(h); if (st) return st;
     return lvi_get_scan_info(h, out);
 }

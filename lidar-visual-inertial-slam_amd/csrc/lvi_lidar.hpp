@@ -54,6 +54,11 @@ struct LidarDev {
 
     // ---- a-0
     lvi_livox_pt* raw = nullptr; int n_raw = 0;            // after dropping the last point
+    // ---- f-1 (IMU deskew): imuDeskewInfo's table, set by lvi_scan_set_deskew
+    bool dk_on = false; int dk_cur = 0; double dk_t0 = 0.0;
+    double* d_dk = nullptr;                                // [4][LVI_DESKEW_MAX_IMU] imuTime, imuRotX, imuRotY, imuRotZ
+    int* d_dk_first = nullptr;                             // message index of the first point that reaches deskewPoint (INT_MAX between scans)
+    float* d_dk_startInv = nullptr;                        // [9] transStartInverse, linear part
     int* blockCnt = nullptr;                               // [N_SCAN][nblk_org]
     int* ringBase = nullptr;                               // [N_SCAN + 1] (kept columns)
     int *startR = nullptr, *endR = nullptr, *d_n = nullptr;

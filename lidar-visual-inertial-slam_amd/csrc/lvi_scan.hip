@@ -24,7 +24,52 @@ struct OrgArgs {
     lvi_pt* pts; float* range; int* col;
     int N_SCAN, H, downsampleRate; float minRange, maxRange;
     int* d_status;
+    // f-1
+    int dk_on, dk_cur; double dk_t0; const double* dk; int* dk_first; float* dk_startInv;
 };
+
+// ---------------------------------------------------------------------------------------------
+// f-1.  deskewPoint (imageProjection.cpp:538-568): rotation of the point's time stamp from the IMU table
+// (findRotation :495-520: the serial scan for the first imuTime > pointTime is a binary search, the table is
+// ascending), Rt = getTransformation(0,0,0,rot), point' = (R0^-1 * Rt) * point with R0 of the first point that
+// reaches deskewPoint.  findPosition returns zeros in the reference, so the translations are zero.
+// sin/cos are taken in double and rounded once: the correctly rounded f32 value the CPU libm returns.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dk_find_rotation(const OrgArgs& a, double pointTime, float rot[3])
+{
+    const double* T = a.dk;
+    int lo = 0, hi = a.dk_cur;                       // first index in [0, cur) whose imuTime > pointTime, else cur
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (pointTime < T[mid]) hi = mid; else lo = mid + 1; }
+    const int f = lo;
+    if (pointTime > T[f] || f == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) rot[d] = (float)a.dk[(1 + d) * LVI_DESKEW_MAX_IMU + f];
+    } else {
+        const int b = f - 1;
+        const double ratioFront = (pointTime - T[b]) / (T[f] - T[b]);
+        const double ratioBack = (T[f] - pointTime) / (T[f] - T[b]);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double* R = a.dk + (1 + d) * LVI_DESKEW_MAX_IMU;
+            rot[d] = (float)(R[f] * ratioFront + R[b] * ratioBack);
+        }
+    }
+}
+__device__ __forceinline__ void dk_rotation(const float rot[3], float R[3][3])      // pcl::getTransformation(0,0,0,roll,pitch,yaw), linear part
+{
+    const float roll = rot[0], pitch = rot[1], yaw = rot[2];
+    const float A = (float)cos((double)yaw), B = (float)sin((double)yaw), C = (float)cos((double)pitch), D = (float)sin((double)pitch),
+                E = (float)cos((double)roll), F = (float)sin((double)roll), DE = D * E, DF = D * F;
+    R[0][0] = A * C; R[0][1] = A * DF - B * E; R[0][2] = B * F + A * DE;
+    R[1][0] = B * C; R[1][1] = A * E + B * DF; R[1][2] = B * DE - A * F;
+    R[2][0] = -D;    R[2][1] = C * F;          R[2][2] = C * E;
+}
+__device__ __forceinline__ double dk_point_time(const OrgArgs& a, unsigned offset_time)
+{
+    const float relTimeF = (float)((double)offset_time * 1e-9);          // PointXYZIRT::time is a float (:255)
+    return a.dk_t0 + (double)relTimeF;
+}
+#define DK_COF(M, i, j) (M[((i) + 1) % 3][((j) + 1) % 3] * M[((i) + 2) % 3][((j) + 2) % 3] - M[((i) + 1) % 3][((j) + 2) % 3] * M[((i) + 2) % 3][((j) + 1) % 3])
 
 __device__ __forceinline__ int org_classify(const OrgArgs& a, const lvi_livox_pt& p, float* range_out)
 {
@@ -43,17 +88,24 @@ __global__ __launch_bounds__(256) void org_count_kernel(OrgArgs a)
     if (threadIdx.x < MAX_N_SCAN) cnt[threadIdx.x] = 0;
     __syncthreads();
     const int base = blockIdx.x * ORG_TILE;
+    int first = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < ORG_TILE / 256; j++) {
         const int i = base + j * 256 + threadIdx.x;
         if (i < a.n_raw) {
             float r;
             const int ring = org_classify(a, a.raw[i], &r);
-            if (ring >= 0) atomicAdd(&cnt[ring], 1);
+            if (ring >= 0) { atomicAdd(&cnt[ring], 1); first = min(first, i); }
         }
     }
     __syncthreads();
     if (threadIdx.x < a.N_SCAN) a.blockCnt[threadIdx.x * a.nblk + blockIdx.x] = cnt[threadIdx.x];
+    if (a.dk_on) {
+        // firstPointFlag (:554): the first point in message order that passes the gates (its column is 0 < Horizon_SCAN)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+        if (lane_id() == 0 && first != 0x7fffffff) atomicMin(a.dk_first, first);
+    }
 }
 
 __global__ __launch_bounds__(256) void org_scan_kernel(OrgArgs a)
@@ -85,6 +137,24 @@ __global__ __launch_bounds__(256) void org_scan_kernel(OrgArgs a)
         }
         a.ringBase[a.N_SCAN] = count;
         *a.d_n = count;
+        if (a.dk_on) {
+            const int fi = *a.dk_first;
+            *a.dk_first = 0x7fffffff;                           // ready for the next scan
+            float Ri[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+            if (fi >= 0 && fi < a.n_raw) {
+                float rot[3], R[3][3];
+                dk_find_rotation(a, dk_point_time(a, a.raw[fi].offset_time), rot);
+                dk_rotation(rot, R);
+                // Eigen::Affine3f::inverse(): cofactor inverse of the 3x3 linear part (Inverse.h, compute_inverse_size3)
+                const float c0 = DK_COF(R, 0, 0), c1 = DK_COF(R, 1, 0), c2 = DK_COF(R, 2, 0);
+                const float det = (c0 * R[0][0] + c1 * R[1][0]) + c2 * R[2][0];
+                const float invdet = 1.0f / det;
+                Ri[0][0] = c0 * invdet; Ri[0][1] = c1 * invdet; Ri[0][2] = c2 * invdet;
+                Ri[1][0] = DK_COF(R, 0, 1) * invdet; Ri[1][1] = DK_COF(R, 1, 1) * invdet; Ri[1][2] = DK_COF(R, 2, 1) * invdet;
+                Ri[2][0] = DK_COF(R, 0, 2) * invdet; Ri[2][1] = DK_COF(R, 1, 2) * invdet; Ri[2][2] = DK_COF(R, 2, 2) * invdet;
+            }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.dk_startInv[i * 3 + j] = Ri[i][j];
+        }
     }
 }
 
@@ -135,6 +205,21 @@ __global__ __launch_bounds__(256) void org_scatter_kernel(OrgArgs a)
         const int colIdn = a.blockCnt[ring[j] * a.nblk + blockIdx.x] + waveCnt[w][ring[j]] + rk[j];   // columnIdnCountVec (:604-605)
         if (colIdn >= a.H) continue;                                                                   // :609
         const int dst = a.ringBase[ring[j]] + colIdn;
+        if (a.dk_on) {
+            const int i = cbase + j * 64 + l;
+            float rot[3], R[3][3], M[3][3];
+            dk_find_rotation(a, dk_point_time(a, a.raw[i].offset_time), rot);
+            dk_rotation(rot, R);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++)           // transBt = transStartInverse * transFinal (:561), three products summed left to right
+                    M[r][c] = (a.dk_startInv[r * 3] * R[0][c] + a.dk_startInv[r * 3 + 1] * R[1][c]) + a.dk_startInv[r * 3 + 2] * R[2][c];
+            const lvi_pt q = p[j];
+            p[j].x = M[0][0] * q.x + M[0][1] * q.y + M[0][2] * q.z + 0.f;       // :564-566
+            p[j].y = M[1][0] * q.x + M[1][1] * q.y + M[1][2] * q.z + 0.f;
+            p[j].z = M[2][0] * q.x + M[2][1] * q.y + M[2][2] * q.z + 0.f;
+        }
         a.pts[dst] = p[j];
         a.range[dst] = rg[j];
         a.col[dst] = colIdn;
@@ -506,6 +591,7 @@ void layout(AR& ar, LidarDev& d)
     const int NS = d.P.N_SCAN;
     d.raw = ar.template alloc<lvi_livox_pt>(d.raw_cap);
     d.blockCnt = ar.template alloc<int>((size_t)NS * d.nblk_org);
+    d.d_dk = ar.template alloc<double>(4 * LVI_DESKEW_MAX_IMU); d.d_dk_first = ar.template alloc<int>(1); d.d_dk_startInv = ar.template alloc<float>(12);
     d.ringBase = ar.template alloc<int>(NS + 1);
     d.startR = ar.template alloc<int>(NS); d.endR = ar.template alloc<int>(NS); d.d_n = ar.template alloc<int>(1);
     d.pts = ar.template alloc<lvi_pt>(d.ext_cap); d.range = ar.template alloc<float>(d.ext_cap); d.col = ar.template alloc<int>(d.ext_cap);
@@ -573,8 +659,9 @@ void lidar_allocate(LidarDev& d)
     d.arena.init(sz.used + (1 << 20));
     layout(d.arena, d);
     LVI_HIP(hipMemsetAsync(d.arena.base, 0, d.arena.size, d.ctx.stream));
-    const int one = 1;
+    const int one = 1, int_max = 0x7fffffff;
     LVI_HIP(hipMemcpyAsync(d.d_fresh, &one, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
+    LVI_HIP(hipMemcpyAsync(d.d_dk_first, &int_max, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
     LVI_HIP(hipHostMalloc((void**)&d.h_icp, sizeof(IcpState), hipHostMallocDefault));
     // static segment tables of the voxel plans
     std::vector<VoxSegStatic> st(std::max(d.P.N_SCAN, 2));
@@ -593,7 +680,8 @@ void lidar_allocate(LidarDev& d)
 void stage_organize(LidarDev& d)
 {
     OrgArgs a{d.raw, d.n_raw, d.blockCnt, d.nblk_org, d.ringBase, d.startR, d.endR, d.d_n, d.pts, d.range, d.col,
-              d.P.N_SCAN, d.P.Horizon_SCAN, d.P.downsampleRate, d.P.lidarMinRange, d.P.lidarMaxRange, d.d_status};
+              d.P.N_SCAN, d.P.Horizon_SCAN, d.P.downsampleRate, d.P.lidarMinRange, d.P.lidarMaxRange, d.d_status,
+              d.dk_on ? 1 : 0, d.dk_cur, d.dk_t0, d.d_dk, d.d_dk_first, d.d_dk_startInv};
     const int nb = std::max(1, div_up(d.n_raw, ORG_TILE));
     const double n = d.n_raw;
     LVI_LAUNCH(d.ctx, "org_count", 20.0 * n, hipLaunchKernelGGL(org_count_kernel, dim3(nb), dim3(256), 0, d.ctx.stream, a));

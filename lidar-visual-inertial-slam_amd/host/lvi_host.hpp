@@ -54,7 +54,30 @@ private:
 class ImageProjection {
 public:
     explicit ImageProjection(LidarHandle& h) : h_(h) {}
-    // cloudHandler for one livox CustomMsg (no IMU deskew: imu_available == false branch of deskewPoint)
+    // imuDeskewInfo (imageProjection.cpp:354-410) on the host: the node keeps its IMU queue; call this with the
+    // queue entries [time, angular velocity] that cover the scan, exactly as the reference loop walks them.
+    // Returns false (deskew off) when fewer than two entries fall into the window, as `imuPointerCur <= 0` does.
+    bool imuDeskewInfo(const double* imu_time, const double* ang_x, const double* ang_y, const double* ang_z, int n_imu,
+                       double timeScanCur, double timeScanEnd)
+    {
+        imuTime_.clear(); rotX_.clear(); rotY_.clear(); rotZ_.clear();
+        for (int i = 0; i < n_imu; ++i) {
+            const double t = imu_time[i];
+            if (t < timeScanCur - 0.01) continue;                          // queue pop :358-364
+            if (t > timeScanEnd + 0.01) break;                             // :378
+            if ((int)imuTime_.size() >= LVI_DESKEW_MAX_IMU) break;
+            if (imuTime_.empty()) { imuTime_.push_back(t); rotX_.push_back(0); rotY_.push_back(0); rotZ_.push_back(0); continue; }   // :381-388
+            const double dt = t - imuTime_.back();                         // :396-400
+            rotX_.push_back(rotX_.back() + ang_x[i] * dt); rotY_.push_back(rotY_.back() + ang_y[i] * dt); rotZ_.push_back(rotZ_.back() + ang_z[i] * dt);
+            imuTime_.push_back(t);
+        }
+        timeScanCur_ = timeScanCur;
+        imu_available_ = imuTime_.size() >= 2;                             // --imuPointerCur; if (imuPointerCur <= 0) return; (:404-408)
+        return imu_available_;
+    }
+    void clearDeskew() { imu_available_ = false; }
+
+    // cloudHandler for one livox CustomMsg; deskews when imuDeskewInfo() found a table for this scan
     CloudInfo cloudHandler(const lvi_livox_pt* points, int32_t point_num, double stamp)
     {
         const int cap = h_.P.N_SCAN * h_.P.Horizon_SCAN;
@@ -63,12 +86,20 @@ public:
         ci.start_ring_index.assign(h_.P.N_SCAN, 0); ci.end_ring_index.assign(h_.P.N_SCAN, 0);
         ci.point_col_ind.assign(cap, 0); ci.point_range.assign(cap, 0.f); ci.cloud_deskewed.resize(cap);
         lvi_scan_info si{cap, 0, ci.start_ring_index.data(), ci.end_ring_index.data(), ci.point_col_ind.data(), ci.point_range.data(), ci.cloud_deskewed.data()};
-        check(lvi_organize_scan(h_.get(), points, point_num, &si), "lvi_organize_scan");
+        if (imu_available_) {
+            lvi_deskew_info dk{1, (int32_t)imuTime_.size() - 1, timeScanCur_, imuTime_.data(), rotX_.data(), rotY_.data(), rotZ_.data()};
+            check(lvi_organize_scan_deskew(h_.get(), points, point_num, &dk, &si), "lvi_organize_scan_deskew");
+        } else {
+            check(lvi_organize_scan(h_.get(), points, point_num, &si), "lvi_organize_scan");
+        }
         ci.cloud_deskewed.resize(si.n);          // point_col_ind / point_range keep their full size as in allocateMemory (:161-162)
         return ci;
     }
 private:
     LidarHandle& h_;
+    bool imu_available_ = false;
+    double timeScanCur_ = 0.0;
+    std::vector<double> imuTime_, rotX_, rotY_, rotZ_;
 };
 
 // ---------------------------------------------------------------------------------------------- FeatureExtraction

@@ -70,6 +70,18 @@ class LidarHotpath:
         self.lib.check(self.lib.dll.lvi_organize_scan(self._h, A._ptr(pts), len(pts), C.byref(si)), "lvi_organize_scan")
         return self._scan_info_dict(si, bufs)
 
+    def organize_scan_deskew(self, livox_pts, time_scan_cur, imu_time, imu_rot):
+        """a-0 + f-1: imu_time [m] / imu_rot [m,3] are imuDeskewInfo's table (imageProjection.cpp:354-410)"""
+        pts = np.ascontiguousarray(livox_pts, dtype=A.LIVOX_DTYPE)
+        t = np.ascontiguousarray(imu_time, np.float64)
+        r = np.ascontiguousarray(np.asarray(imu_rot, np.float64).T)
+        dp = C.POINTER(C.c_double)
+        info = A.DeskewInfo(1, len(t) - 1, float(time_scan_cur), t.ctypes.data_as(dp), r[0].ctypes.data_as(dp),
+                            r[1].ctypes.data_as(dp), r[2].ctypes.data_as(dp))
+        si, bufs = self._new_scan_info()
+        self.lib.check(self.lib.dll.lvi_organize_scan_deskew(self._h, A._ptr(pts), len(pts), C.byref(info), C.byref(si)), "lvi_organize_scan_deskew")
+        return self._scan_info_dict(si, bufs)
+
     def extract_features(self, info):
         n = int(info["n"])
         keep = dict(start=np.ascontiguousarray(info["start_ring_index"], np.int32), end=np.ascontiguousarray(info["end_ring_index"], np.int32),
@@ -143,6 +155,18 @@ class LidarHotpath:
 
     def scan_organize(self):
         self.lib.check(self.lib.dll.lvi_scan_organize(self._h), "lvi_scan_organize")
+
+    def scan_set_deskew(self, time_scan_cur=0.0, imu_time=None, imu_rot=None):
+        """f-1: imuDeskewInfo's table (imu_time [m], imu_rot [m,3], seconds / radians); None switches deskew off"""
+        if imu_time is None:
+            self.lib.check(self.lib.dll.lvi_scan_set_deskew(self._h, None), "lvi_scan_set_deskew")
+            return
+        t = np.ascontiguousarray(imu_time, np.float64)
+        r = np.ascontiguousarray(np.asarray(imu_rot, np.float64).T)          # rows: x, y, z
+        dp = C.POINTER(C.c_double)
+        info = A.DeskewInfo(1, len(t) - 1, float(time_scan_cur), t.ctypes.data_as(dp), r[0].ctypes.data_as(dp),
+                            r[1].ctypes.data_as(dp), r[2].ctypes.data_as(dp))
+        self.lib.check(self.lib.dll.lvi_scan_set_deskew(self._h, C.byref(info)), "lvi_scan_set_deskew")
 
     def scan_extract(self):
         self.lib.check(self.lib.dll.lvi_scan_extract(self._h), "lvi_scan_extract")

@@ -51,6 +51,11 @@ struct lvi_lidar {
     std::vector<int32_t> col;                        // cloudInfo.point_col_ind
     std::vector<int32_t> startR, endR;
     bool have_org = false;
+    // ---- f-1 (imuDeskewInfo's table, imageProjection.cpp:77-80)
+    bool imu_available = false;
+    int imuPointerCur = 0;
+    double timeScanCur = 0.0;
+    std::vector<double> imuTime, imuRotX, imuRotY, imuRotZ;
     // ---- a-1..a-3 (arrays persist across scans: featureExtraction.cpp:59,67-69)
     std::vector<smoothness_t> cloudSmoothness;
     std::vector<float> cloudCurvature;
@@ -82,10 +87,74 @@ namespace {
 inline float pointDistance(const lvi_pt& p) { return std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z); }   // utility.h:403-406
 
 // ---------------------------------------------------------------------------
-// a-0  imageProjection.cpp:570-647 (sensor == LIVOX, imu_available == false → deskewPoint returns the point)
+// f-1  findRotation (imageProjection.cpp:495-520) and deskewPoint (:538-568).  findPosition (:522-536) returns
+// zeros (its body is commented out in the reference), so every transform here has a zero translation.
+// Eigen pieces restated (Eigen 3.4, not in the reference tree, PARITY UNPINNED): Affine3f::inverse() =
+// 3x3 cofactor inverse of the linear part (Inverse.h compute_inverse_size3), Affine3f * Affine3f =
+// linear * linear with the three products of an element summed left to right.
+// ---------------------------------------------------------------------------
+void findRotation(const lvi_lidar* h, double pointTime, float* rotXCur, float* rotYCur, float* rotZCur)
+{
+    *rotXCur = 0; *rotYCur = 0; *rotZCur = 0;
+    int imuPointerFront = 0;
+    while (imuPointerFront < h->imuPointerCur) {
+        if (pointTime < h->imuTime[imuPointerFront]) break;
+        ++imuPointerFront;
+    }
+    if (pointTime > h->imuTime[imuPointerFront] || imuPointerFront == 0) {
+        *rotXCur = (float)h->imuRotX[imuPointerFront];
+        *rotYCur = (float)h->imuRotY[imuPointerFront];
+        *rotZCur = (float)h->imuRotZ[imuPointerFront];
+    } else {
+        int imuPointerBack = imuPointerFront - 1;
+        double ratioFront = (pointTime - h->imuTime[imuPointerBack]) / (h->imuTime[imuPointerFront] - h->imuTime[imuPointerBack]);
+        double ratioBack = (h->imuTime[imuPointerFront] - pointTime) / (h->imuTime[imuPointerFront] - h->imuTime[imuPointerBack]);
+        *rotXCur = (float)(h->imuRotX[imuPointerFront] * ratioFront + h->imuRotX[imuPointerBack] * ratioBack);
+        *rotYCur = (float)(h->imuRotY[imuPointerFront] * ratioFront + h->imuRotY[imuPointerBack] * ratioBack);
+        *rotZCur = (float)(h->imuRotZ[imuPointerFront] * ratioFront + h->imuRotZ[imuPointerBack] * ratioBack);
+    }
+}
+
+struct Mat3f { float m[3][3]; };
+
+inline float cofactor3(const Mat3f& a, int i, int j)
+{
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return a.m[i1][j1] * a.m[i2][j2] - a.m[i1][j2] * a.m[i2][j1];
+}
+inline Mat3f inverse3(const Mat3f& a)
+{
+    const float c0 = cofactor3(a, 0, 0), c1 = cofactor3(a, 1, 0), c2 = cofactor3(a, 2, 0);
+    const float det = (c0 * a.m[0][0] + c1 * a.m[1][0]) + c2 * a.m[2][0];
+    const float invdet = 1.0f / det;
+    Mat3f r;
+    r.m[0][0] = c0 * invdet; r.m[0][1] = c1 * invdet; r.m[0][2] = c2 * invdet;
+    r.m[1][0] = cofactor3(a, 0, 1) * invdet; r.m[1][1] = cofactor3(a, 1, 1) * invdet; r.m[1][2] = cofactor3(a, 2, 1) * invdet;
+    r.m[2][0] = cofactor3(a, 0, 2) * invdet; r.m[2][1] = cofactor3(a, 1, 2) * invdet; r.m[2][2] = cofactor3(a, 2, 2) * invdet;
+    return r;
+}
+inline Mat3f mul3(const Mat3f& a, const Mat3f& b)
+{
+    Mat3f r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r.m[i][j] = (a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j];
+    return r;
+}
+inline Mat3f rotationOf(float rotX, float rotY, float rotZ)
+{
+    const lvo::Affine3f t = lvo::getTransformation(0.f, 0.f, 0.f, rotX, rotY, rotZ);       // posCur = 0 (:522-536)
+    Mat3f r;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = t.m[i][j];
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// a-0  imageProjection.cpp:570-647 (sensor == LIVOX)
 // ---------------------------------------------------------------------------
 void organize(lvi_lidar* h)
 {
+    bool firstPointFlag = true;                                             // resetParameters
+    Mat3f transStartInverse{};
     const lvi_lidar_params& P = h->P;
     const int N_SCAN = P.N_SCAN, H = P.Horizon_SCAN;
     std::vector<float> rangeMat((size_t)N_SCAN * H, FLT_MAX);
@@ -106,6 +175,22 @@ void organize(lvi_lidar* h)
         columnIdnCountVec[rowIdn] += 1;
         if (columnIdn < 0 || columnIdn >= H) continue;                      // :609
         if (rangeMat[(size_t)rowIdn * H + columnIdn] != FLT_MAX) continue;  // :612
+        if (h->imu_available) {                                             // deskewPoint :538-568 (deskewFlag stays 0, :109)
+            const float relTimeF = (float)(h->raw[i].offset_time * 1e-9);   // PointXYZIRT::time is a float (:255)
+            const double pointTime = h->timeScanCur + (double)relTimeF;
+            float rotXCur, rotYCur, rotZCur;
+            findRotation(h, pointTime, &rotXCur, &rotYCur, &rotZCur);
+            const Mat3f transFinal = rotationOf(rotXCur, rotYCur, rotZCur);
+            if (firstPointFlag) { transStartInverse = inverse3(transFinal); firstPointFlag = false; }
+            const Mat3f transBt = mul3(transStartInverse, transFinal);
+            const float tx = 0.f;                                           // lhs.linear * 0 + (-(inv * 0)) = +0
+            lvi_pt np;
+            np.x = transBt.m[0][0] * thisPoint.x + transBt.m[0][1] * thisPoint.y + transBt.m[0][2] * thisPoint.z + tx;
+            np.y = transBt.m[1][0] * thisPoint.x + transBt.m[1][1] * thisPoint.y + transBt.m[1][2] * thisPoint.z + tx;
+            np.z = transBt.m[2][0] * thisPoint.x + transBt.m[2][1] * thisPoint.y + transBt.m[2][2] * thisPoint.z + tx;
+            np.intensity = thisPoint.intensity;
+            thisPoint = np;
+        }
         rangeMat[(size_t)rowIdn * H + columnIdn] = range;
         fullCloud[(size_t)columnIdn + (size_t)rowIdn * H] = thisPoint;      // :619-620
     }
@@ -793,10 +878,35 @@ int32_t lvi_get_pose_record(lvi_lidar* h, lvi_pose_record* out)
     return LVI_OK;
 }
 
+int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    h->imu_available = false;
+    if (!info || !info->imu_available) return LVI_OK;
+    if (info->imu_pointer_cur < 1 || info->imu_pointer_cur >= LVI_DESKEW_MAX_IMU || !info->imu_time || !info->imu_rot_x || !info->imu_rot_y || !info->imu_rot_z)
+        return fail(LVI_ERR_INVALID_ARG, "bad deskew table");
+    const int m = info->imu_pointer_cur + 1;
+    h->imuTime.assign(info->imu_time, info->imu_time + m);
+    h->imuRotX.assign(info->imu_rot_x, info->imu_rot_x + m);
+    h->imuRotY.assign(info->imu_rot_y, info->imu_rot_y + m);
+    h->imuRotZ.assign(info->imu_rot_z, info->imu_rot_z + m);
+    h->imuPointerCur = info->imu_pointer_cur; h->timeScanCur = info->time_scan_cur;
+    h->imu_available = true;
+    return LVI_OK;
+}
+
 // ---- one-call forms --------------------------------------------------------
 int32_t lvi_organize_scan(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw, lvi_scan_info* out)
 {
-    int32_t st = lvi_scan_upload(h, pts, n_raw); if (st) return st;
+    int32_t st = lvi_scan_set_deskew(h, nullptr); if (st) return st;
+    st = lvi_scan_upload(h, pts, n_raw); if (st) return st;
+    st = lvi_scan_organize(h); if (st) return st;
+    return lvi_get_scan_info(h, out);
+}
+int32_t lvi_organize_scan_deskew(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw, const lvi_deskew_info* info, lvi_scan_info* out)
+{
+    int32_t st = lvi_scan_set_deskew(h, info); if (st) return st;
+    st = lvi_scan_upload(h, pts, n_raw); if (st) return st;
     st = lvi_scan_organize(h); if (st) return st;
     return lvi_get_scan_info(h, out);
 }

@@ -63,6 +63,38 @@ def test_organize_edge_cases(pkg, oracle, hip):
     o.close(); g.close()
 
 
+# ----------------------------------------------------------------------------- f-1
+def test_deskew_matches_oracle(pkg, oracle, hip):
+    """IMU deskew inside organise: ranges / columns / ring bounds bit-exact; points bit-exact wherever the device's
+    double-rounded sin/cos equal libm's (all but a handful of angles), within 2 ulp of the coordinate scale otherwise"""
+    S = pkg.synth
+    o = pkg.LidarHotpath(oracle, **small_params()); g = pkg.LidarHotpath(hip, **small_params())
+    scan = S.make_scan(20001, S.loop_pose(0.7, 0.01, -0.02), 77)
+    t0 = 1234.5
+    t = np.arange(t0 - 0.003, t0 + 0.12, 1.0 / 200.0)
+    rng = np.random.default_rng(3)
+    w = np.cumsum(rng.normal(0, 0.3, (len(t), 3)), axis=0) * 0.05 + [0.3, -0.2, 0.9]          # wandering angular velocity
+    rot = np.concatenate([[np.zeros(3)], np.cumsum(w[1:] * np.diff(t)[:, None], axis=0)])
+    a = o.organize_scan_deskew(scan, t0, t, rot)
+    b = g.organize_scan_deskew(scan, t0, t, rot)
+    assert a["n"] == b["n"] > 15000
+    for k in ("start_ring_index", "end_ring_index", "point_col_ind"):
+        np.testing.assert_array_equal(a[k], b[k])
+    np.testing.assert_array_equal(bits(a["point_range"]), bits(b["point_range"]))
+    pa, pb = xyzi(a["cloud_deskewed"]), xyzi(b["cloud_deskewed"])
+    np.testing.assert_array_equal(pa[:, 3], pb[:, 3])
+    assert np.abs(pa[:, :3] - pb[:, :3]).max() <= 4e-6 * np.abs(pa[:, :3]).max()
+    assert (pa[:, :3].view(np.uint32) == pb[:, :3].view(np.uint32)).mean() > 0.98
+    # and the whole path keeps working on the deskewed cloud (staged form)
+    for h in (o, g):
+        h.scan_set_deskew(t0, t, rot); h.scan_upload(scan); h.scan_organize(); h.scan_extract()
+    (co, so), (cg, sg) = o.get_features(), g.get_features()
+    assert len(co) == len(cg) and len(so) == len(sg)
+    # plain organise afterwards is not deskewed
+    np.testing.assert_array_equal(xyzi(o.organize_scan(scan)["cloud_deskewed"]).view(np.uint32), xyzi(g.organize_scan(scan)["cloud_deskewed"]).view(np.uint32))
+    o.close(); g.close()
+
+
 # ----------------------------------------------------------------------------- a-1..a-3
 def test_smoothness_and_occlusion_bit_exact(pkg, pair, scene):
     A = pkg._abi

@@ -54,6 +54,73 @@ def test_organize_horizon_truncation(pkg, oracle):
     h.close()
 
 
+# ----------------------------------------------------------------------------- f-1 (IMU deskew)
+def _imu_table(t0, t1, rate_hz, omega):
+    """imuDeskewInfo (imageProjection.cpp:354-410) for a constant angular velocity omega [rad/s]: rot = omega * (t - t[0])"""
+    t = np.arange(t0, t1 + 1e-9, 1.0 / rate_hz)
+    return t, (t - t[0])[:, None] * np.asarray(omega, np.float64)[None, :]
+
+
+def test_deskew_zero_rotation_is_identity(pkg, L):
+    S = pkg.synth
+    scan = S.make_scan(3001, S.loop_pose(0.3), 5)
+    t, rot = _imu_table(99.99, 100.12, 200.0, [0, 0, 0])
+    a = L.organize_scan(scan)
+    b = L.organize_scan_deskew(scan, 100.0, t, rot)
+    np.testing.assert_array_equal(xyzi(a["cloud_deskewed"]).view(np.uint32), xyzi(b["cloud_deskewed"]).view(np.uint32))
+    np.testing.assert_array_equal(a["point_col_ind"], b["point_col_ind"])
+    c = L.organize_scan(scan)                      # the plain entry switches deskew off again
+    np.testing.assert_array_equal(xyzi(a["cloud_deskewed"]).view(np.uint32), xyzi(c["cloud_deskewed"]).view(np.uint32))
+
+
+def test_deskew_constant_yaw_rate_against_float64(pkg, L):
+    """deskewPoint (:538-568): p' = R(rot(t_first))^-1 R(rot(t)) p with rot interpolated in the table (:495-520)"""
+    S = pkg.synth
+    scan = S.make_scan(4001, S.loop_pose(1.1), 9)
+    t0 = 250.0
+    omega = np.array([0.0, 0.0, 0.8])
+    t, rot = _imu_table(t0 - 0.004, t0 + 0.12, 400.0, omega)
+    info = L.organize_scan_deskew(scan, t0, t, rot)
+    plain = L.organize_scan(scan)
+    assert info["n"] == plain["n"] > 3000
+    np.testing.assert_array_equal(info["point_range"].view(np.uint32), plain["point_range"].view(np.uint32))   # range is taken before the deskew (:582,:616)
+    # independent float64 model: per-point time, linear interpolation of the table, yaw-only rotation
+    kept = scan[:-1]
+    rng = np.sqrt(kept["x"].astype(np.float64) ** 2 + kept["y"].astype(np.float64) ** 2 + kept["z"].astype(np.float64) ** 2)
+    ok = (rng >= 1.0) & (rng <= 100.0)
+    tt = t0 + (kept["offset_time"].astype(np.float64) * 1e-9).astype(np.float32).astype(np.float64)
+    yaw = np.interp(tt, t, rot[:, 2])
+    first = np.flatnonzero(ok)[0]
+    dy = yaw - yaw[first]
+    x = kept["x"] * np.cos(dy) - kept["y"] * np.sin(dy)
+    y = kept["x"] * np.sin(dy) + kept["y"] * np.cos(dy)
+    want = []
+    for ring in range(4):
+        m = ok & (kept["line"] == ring)
+        want.append(np.stack([x[m], y[m], kept["z"][m].astype(np.float64)], axis=1))
+    want = np.concatenate(want)
+    got = xyzi(info["cloud_deskewed"])[:, :3].astype(np.float64)
+    assert np.abs(got - want).max() < 2e-5
+    assert np.abs(got - xyzi(plain["cloud_deskewed"])[:, :3]).max() > 0.05       # the deskew did something
+
+
+def test_deskew_table_edges(pkg, L):
+    """point times before the first / after the last table entry take that entry (:507-511)"""
+    xyz = [[5, 0, 0], [0, 6, 0], [4, 4, 0], [0, 0, 0]]
+    p = _livox(pkg, xyz, [0, 0, 0, 0])
+    p["offset_time"] = [0, 50_000_000, 100_000_000, 0]
+    t = np.array([10.02, 10.04, 10.06])                       # all three point times: 10.00 (before), 10.05 (inside), 10.10 (after)
+    rot = np.array([[0, 0, 0.0], [0, 0, 0.1], [0, 0, 0.3]])
+    info = L.organize_scan_deskew(p, 10.0, t, rot)
+    got = xyzi(info["cloud_deskewed"])[:, :3].astype(np.float64)
+    for k, yaw in enumerate([0.0, 0.2, 0.3]):                 # first point: entry 0 (yaw 0) is the reference frame
+        c, s = np.cos(yaw), np.sin(yaw)
+        want = [xyz[k][0] * c - xyz[k][1] * s, xyz[k][0] * s + xyz[k][1] * c, 0.0]
+        assert np.abs(got[k] - want).max() < 1e-5, (k, got[k], want)
+    with pytest.raises(Exception):
+        L.organize_scan_deskew(p, 10.0, t[:1], rot[:1])       # imuPointerCur <= 0 is "not available" in the reference (:406)
+
+
 # ----------------------------------------------------------------------------- a-1, a-2
 def test_smoothness_and_occlusion_against_numpy(pkg, L):
     A = pkg._abi
