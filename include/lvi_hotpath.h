@@ -291,6 +291,11 @@ typedef struct lvi_tracker_params {
     int32_t max_features;            /* capacity of the per-frame point arrays */
 } lvi_tracker_params;
 
+/* f-3: MEI (unified omnidirectional) camera, camera_model CataCamera::Parameters (CataCamera.cc:14-40). */
+typedef struct lvi_mei_params {
+    double xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0;
+} lvi_mei_params;
+
 typedef struct lvi_tracker lvi_tracker;    /* opaque */
 
 void    lvi_tracker_params_default(lvi_tracker_params *p);
@@ -311,6 +316,19 @@ int32_t lvi_good_features(lvi_tracker *t, const uint8_t *img, const uint8_t *mas
 /* staged form mirroring FeatureTracker::readImage's image rotation
  * (feature_tracker.cpp:94-101, 200-204): push makes the new image "forw"
  * (its pyramid is built once and kept resident), the previous forw becomes "cur". */
+/* f-2  cv::createCLAHE(3.0, cv::Size(8, 8))->apply(_img, img)  (feature_tracker.cpp:86-90, EQUALIZE = 1).
+ *      One-call form: host image in, host image out. */
+int32_t lvi_clahe(lvi_tracker *t, const uint8_t *img, int32_t w, int32_t h, int32_t stride,
+                  double clip_limit, int32_t tiles_x, int32_t tiles_y, uint8_t *out, int32_t out_stride);
+/* f-2 staged: every later lvi_tracker_push_image equalises the frame on the device before the pyramid is built
+ *      (readImage's `if (EQUALIZE)` branch); on = 0 restores `img = _img`. */
+int32_t lvi_tracker_set_equalize(lvi_tracker *t, int32_t on, double clip_limit, int32_t tiles_x, int32_t tiles_y);
+
+/* f-3  undistortedPoints(): m_camera->liftProjective(a, b); cur_un_pts = (b.x/b.z, b.y/b.z)
+ *      (feature_tracker.cpp:298-311; CataCamera::liftProjective CataCamera.cc:556-626, distortion :766-783).
+ *      xy / un_xy: n packed (x, y) f32 pairs, as std::vector<cv::Point2f>. */
+int32_t lvi_undistort_points(lvi_tracker *t, const lvi_mei_params *cam, const float *xy, int32_t n, float *un_xy);
+
 int32_t lvi_tracker_push_image(lvi_tracker *t, const uint8_t *img, int32_t w, int32_t h, int32_t stride);
 int32_t lvi_tracker_set_points(lvi_tracker *t, const float *cur_xy, int32_t n);                   /* H2D cur_pts */
 int32_t lvi_tracker_run_lk(lvi_tracker *t);                                                        /* cur → forw, device-resident */

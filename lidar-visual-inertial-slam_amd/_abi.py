@@ -60,6 +60,10 @@ class DeskewInfo(C.Structure):
                 ("imu_rot_y", C.POINTER(C.c_double)), ("imu_rot_z", C.POINTER(C.c_double))]
 
 
+class MeiParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("xi", "k1", "k2", "p1", "p2", "gamma1", "gamma2", "u0", "v0")]
+
+
 class Cloud(C.Structure):
     _fields_ = [("capacity", C.c_int32), ("n", C.c_int32), ("pts", C.c_void_p)]
 
@@ -135,6 +139,9 @@ SIGNATURES = {
     "lvi_lk_track": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "lvi_good_features": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f64, _f64, _vp, _i32, _P(_i32)]),
     "lvi_tracker_push_image": (_i32, [_vp, _vp, _i32, _i32, _i32]),
+    "lvi_clahe": (_i32, [_vp, _vp, _i32, _i32, _i32, C.c_double, _i32, _i32, _vp, _i32]),
+    "lvi_tracker_set_equalize": (_i32, [_vp, _i32, C.c_double, _i32, _i32]),
+    "lvi_undistort_points": (_i32, [_vp, _P(MeiParams), _vp, _i32, _vp]),
     "lvi_tracker_set_points": (_i32, [_vp, _vp, _i32]),
     "lvi_tracker_run_lk": (_i32, [_vp]),
     "lvi_tracker_get_lk": (_i32, [_vp, _vp, _vp, _vp, _i32, _P(_i32)]),

@@ -66,6 +66,106 @@ struct LkArgs {
 __device__ __forceinline__ int cv_floor(float v) { const int i = (int)v; return i - (i > v); }
 __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
 
+// ---------------------------------------------------------------------------------------------
+// f-2  cv::CLAHE::apply, CV_8UC1 (OpenCV imgproc/src/clahe.cpp).  clahe_lut: one workgroup per tile — LDS
+// histogram, clip + redistribution evaluated per bin (the serial residual loop hits bins 0, step, 2·step, …),
+// inclusive scan, lut = saturate(cvRound(sum * lutScale)).  clahe_interp: one thread per pixel, the f32 blend of
+// the four surrounding tile LUTs in the reference's operation order (the library is built -ffp-contract=off).
+// ---------------------------------------------------------------------------------------------
+struct ClaheArgs {
+    const uint8_t* src; uint8_t* dst; uint8_t* lut;
+    int W, H, tilesX, tilesY, tw, th, clipLimit; float lutScale;
+};
+
+__global__ __launch_bounds__(256) void clahe_lut_kernel(ClaheArgs a)
+{
+    __shared__ int hist[256];
+    __shared__ int ws[8];
+    const int k = blockIdx.x, tx = k % a.tilesX, ty = k / a.tilesX, tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    const int area = a.tw * a.th;
+    for (int idx = tid; idx < area; idx += 256) {
+        const int x = tx * a.tw + idx % a.tw, y = ty * a.th + idx / a.tw;
+        // right / bottom extension of images that are not a multiple of the tile grid: BORDER_REFLECT_101
+        const int sx = x < a.W ? x : reflect101(x, a.W), sy = y < a.H ? y : reflect101(y, a.H);
+        atomicAdd(&hist[a.src[(size_t)sy * a.W + sx]], 1);
+    }
+    __syncthreads();
+    int hv = hist[tid];
+    if (a.clipLimit > 0) {
+        const int excess = max(hv - a.clipLimit, 0);
+        hv = min(hv, a.clipLimit);
+        int clipped;
+        (void)block_excl_scan<256>(excess, ws, &clipped);
+        const int redistBatch = clipped / 256;
+        const int residual = clipped - redistBatch * 256;
+        hv += redistBatch;
+        if (residual != 0) {
+            const int step = max(256 / residual, 1);
+            if (tid % step == 0 && tid / step < residual) hv++;
+        }
+    }
+    int tot;
+    const int sum = block_excl_scan<256>(hv, ws, &tot) + hv;
+    const int v = cv_round((float)sum * a.lutScale);
+    a.lut[(size_t)k * 256 + tid] = (uint8_t)min(max(v, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void clahe_interp_kernel(ClaheArgs a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const float inv_tw = 1.0f / a.tw, inv_th = 1.0f / a.th;
+    const float tyf = (float)y * inv_th - 0.5f;
+    int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0); ty2 = min(ty2, a.tilesY - 1);
+    const float txf = (float)x * inv_tw - 0.5f;
+    int tx1 = cv_floor(txf), tx2 = tx1 + 1;
+    const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0); tx2 = min(tx2, a.tilesX - 1);
+    const int srcVal = a.src[(size_t)y * a.W + x];
+    const uint8_t* p1 = a.lut + (size_t)ty1 * a.tilesX * 256;
+    const uint8_t* p2 = a.lut + (size_t)ty2 * a.tilesX * 256;
+    const int ind1 = tx1 * 256 + srcVal, ind2 = tx2 * 256 + srcVal;
+    const float res = ((float)p1[ind1] * xa1 + (float)p1[ind2] * xa) * ya1 + ((float)p2[ind1] * xa1 + (float)p2[ind2] * xa) * ya;
+    a.dst[(size_t)y * a.W + x] = (uint8_t)min(max(cv_round(res), 0), 255);
+}
+
+// ---------------------------------------------------------------------------------------------
+// f-3  CataCamera::liftProjective with the 8-step recursive distortion model + (b.x/b.z, b.y/b.z) → Point2f
+// (CataCamera.cc:556-626, 766-783; feature_tracker.cpp:306-309).  All in double, one thread per point.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mei_distortion(const lvi_mei_params& c, double pux, double puy, double& dux, double& duy)
+{
+    const double mx2_u = pux * pux, my2_u = puy * puy, mxy_u = pux * puy;
+    const double rho2_u = mx2_u + my2_u;
+    const double rad_dist_u = c.k1 * rho2_u + c.k2 * rho2_u * rho2_u;
+    dux = pux * rad_dist_u + 2.0 * c.p1 * mxy_u + c.p2 * (rho2_u + 2.0 * mx2_u);
+    duy = puy * rad_dist_u + 2.0 * c.p2 * mxy_u + c.p1 * (rho2_u + 2.0 * my2_u);
+}
+
+__global__ __launch_bounds__(64) void mei_undistort_kernel(lvi_mei_params c, const float* __restrict__ xy, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const double inv_K11 = 1.0 / c.gamma1, inv_K13 = -c.u0 / c.gamma1, inv_K22 = 1.0 / c.gamma2, inv_K23 = -c.v0 / c.gamma2;
+    const bool noDistortion = c.k1 == 0.0 && c.k2 == 0.0 && c.p1 == 0.0 && c.p2 == 0.0;
+    const double mx_d = inv_K11 * (double)xy[2 * i] + inv_K13, my_d = inv_K22 * (double)xy[2 * i + 1] + inv_K23;
+    double mx_u = mx_d, my_u = my_d;
+    if (!noDistortion) {
+        double dux, duy;
+        mei_distortion(c, mx_d, my_d, dux, duy);
+        mx_u = mx_d - dux; my_u = my_d - duy;
+        for (int it = 1; it < 8; ++it) { mei_distortion(c, mx_u, my_u, dux, duy); mx_u = mx_d - dux; my_u = my_d - duy; }
+    }
+    double bz;
+    if (c.xi == 1.0) bz = (1.0 - mx_u * mx_u - my_u * my_u) / 2.0;
+    else { const double rho2_d = mx_u * mx_u + my_u * my_u; bz = 1.0 - c.xi * (rho2_d + 1.0) / (c.xi + sqrt(1.0 + (1.0 - c.xi * c.xi) * rho2_d)); }
+    out[2 * i] = (float)(mx_u / bz); out[2 * i + 1] = (float)(my_u / bz);
+}
+
 __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
 {
     constexpr int TW = LK_WIN_MAX + 3;             // 24: source tile (window + 1 for bilinear + 1 on each side for Scharr)
@@ -426,6 +526,8 @@ int32_t tfail(int32_t code, const std::string& msg) { set_error(msg); return cod
 
 using namespace lvi;
 
+constexpr int CLAHE_MAX_TILES = 64;
+
 struct lvi_tracker {
     lvi_tracker_params P;
     int device = 0;
@@ -441,6 +543,9 @@ struct lvi_tracker {
     float* d_gftt_xy = nullptr;
     SortPlan sort;
     int gftt_n = 0, gftt_ncand = 0;
+    // f-2 / f-3
+    uint8_t *d_eq = nullptr, *d_lut = nullptr; float *d_un_in = nullptr, *d_un_out = nullptr;
+    bool equalize = false; double clahe_clip = 3.0; int clahe_tx = 8, clahe_ty = 8;
 };
 
 namespace {
@@ -479,6 +584,25 @@ void tracker_layout(AR& ar, lvi_tracker& t)
     t.d_out_n = ar.template alloc<int>(1); t.d_ncand = ar.template alloc<int>(1);
     t.d_gftt_xy = ar.template alloc<float>(2 * (size_t)F);
     t.sort.allocate(ar, 1, W * H);
+    t.d_stage = ar.template alloc<uint8_t>((size_t)W * H); t.d_eq = ar.template alloc<uint8_t>((size_t)W * H);
+    t.d_lut = ar.template alloc<uint8_t>((size_t)CLAHE_MAX_TILES * CLAHE_MAX_TILES * 256);
+    t.d_un_in = ar.template alloc<float>(2 * (size_t)F); t.d_un_out = ar.template alloc<float>(2 * (size_t)F);
+}
+
+// src (w x h, dense) → dst equalised; both device buffers of the handle
+void run_clahe(lvi_tracker& t, const uint8_t* src, uint8_t* dst, int w, int h, double clip, int tilesX, int tilesY)
+{
+    int extW = w, extH = h;
+    if (w % tilesX != 0 || h % tilesY != 0) { extW = w + (tilesX - (w % tilesX)); extH = h + (tilesY - (h % tilesY)); }   // copyMakeBorder quirk: both sides grow
+    ClaheArgs a{};
+    a.src = src; a.dst = dst; a.lut = t.d_lut; a.W = w; a.H = h; a.tilesX = tilesX; a.tilesY = tilesY;
+    a.tw = extW / tilesX; a.th = extH / tilesY;
+    const int area = a.tw * a.th;
+    a.lutScale = static_cast<float>(255) / area;
+    a.clipLimit = 0;
+    if (clip > 0.0) a.clipLimit = std::max(static_cast<int>(clip * area / 256), 1);
+    LVI_LAUNCH(t.ctx, "clahe_lut", (double)w * h, hipLaunchKernelGGL(clahe_lut_kernel, dim3(tilesX * tilesY), dim3(256), 0, t.ctx.stream, a));
+    LVI_LAUNCH(t.ctx, "clahe_interp", 2.0 * w * h, hipLaunchKernelGGL(clahe_interp_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, t.ctx.stream, a));
 }
 
 void build_pyramid(lvi_tracker& t, int slot)
@@ -563,7 +687,12 @@ int32_t lvi_tracker_push_image(lvi_tracker* t, const uint8_t* img, int32_t w, in
         if (t->have_forw && (w != t->w || h != t->h)) { t->have_forw = t->have_cur = false; }
         if (t->have_forw) { std::swap(t->cur, t->forw); t->have_cur = true; }     // cur_img = forw_img (:203)
         t->w = w; t->h = h;
-        LVI_HIP(hipMemcpy2DAsync(t->pyr[t->forw].lv[0].px, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
+        if (t->equalize) {                                                         // readImage's EQUALIZE branch (:86-90)
+            LVI_HIP(hipMemcpy2DAsync(t->d_stage, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
+            run_clahe(*t, t->d_stage, t->pyr[t->forw].lv[0].px, w, h, t->clahe_clip, t->clahe_tx, t->clahe_ty);
+        } else {
+            LVI_HIP(hipMemcpy2DAsync(t->pyr[t->forw].lv[0].px, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
+        }
         build_pyramid(*t, t->forw);
         if (!t->have_forw) {                                                       // prev = cur = forw = img (:94-97)
             LVI_HIP(hipMemcpyAsync(t->pyr[t->cur].lv[0].px, t->pyr[t->forw].lv[0].px, (size_t)w * h, hipMemcpyDeviceToDevice, t->ctx.stream));
@@ -572,6 +701,43 @@ int32_t lvi_tracker_push_image(lvi_tracker* t, const uint8_t* img, int32_t w, in
         }
         LVI_HIP(hipStreamSynchronize(t->ctx.stream));                               // caller may reuse its buffer
         t->have_forw = true; t->have_lk = false; t->have_gftt = false;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_clahe(lvi_tracker* t, const uint8_t* img, int32_t w, int32_t h, int32_t stride, double clip_limit, int32_t tiles_x, int32_t tiles_y,
+                  uint8_t* out, int32_t out_stride)
+{
+    if (!t || !img || !out || w <= 0 || h <= 0 || stride < w || out_stride < w) return tfail(LVI_ERR_INVALID_ARG, "bad image");
+    if (tiles_x < 1 || tiles_y < 1 || tiles_x > CLAHE_MAX_TILES || tiles_y > CLAHE_MAX_TILES) return tfail(LVI_ERR_INVALID_ARG, "bad tile grid");
+    if (w > t->P.max_width || h > t->P.max_height) return tfail(LVI_ERR_CAPACITY, "image exceeds capacity");
+    return tguard(t, [&]() -> int32_t {
+        LVI_HIP(hipMemcpy2DAsync(t->d_stage, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
+        run_clahe(*t, t->d_stage, t->d_eq, w, h, clip_limit, tiles_x, tiles_y);
+        LVI_HIP(hipMemcpy2DAsync(out, (size_t)out_stride, t->d_eq, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_set_equalize(lvi_tracker* t, int32_t on, double clip_limit, int32_t tiles_x, int32_t tiles_y)
+{
+    if (!t) return tfail(LVI_ERR_INVALID_ARG, "null handle");
+    if (on && (tiles_x < 1 || tiles_y < 1 || tiles_x > CLAHE_MAX_TILES || tiles_y > CLAHE_MAX_TILES)) return tfail(LVI_ERR_INVALID_ARG, "bad tile grid");
+    t->equalize = on != 0; t->clahe_clip = clip_limit; t->clahe_tx = tiles_x; t->clahe_ty = tiles_y;
+    return LVI_OK;
+}
+
+int32_t lvi_undistort_points(lvi_tracker* t, const lvi_mei_params* cam, const float* xy, int32_t n, float* un_xy)
+{
+    if (!t || !cam || n < 0 || (n > 0 && (!xy || !un_xy))) return tfail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (n > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many points");
+    if (n == 0) return LVI_OK;
+    return tguard(t, [&]() -> int32_t {
+        LVI_HIP(hipMemcpyAsync(t->d_un_in, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
+        LVI_LAUNCH(t->ctx, "mei_undistort", 16.0 * n, hipLaunchKernelGGL(mei_undistort_kernel, dim3(div_up(n, 64)), dim3(64), 0, t->ctx.stream, *cam, t->d_un_in, n, t->d_un_out));
+        LVI_HIP(hipMemcpyAsync(un_xy, t->d_un_out, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, t->ctx.stream));
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
         return LVI_OK;
     });
 }

@@ -14,6 +14,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "../../include/lvi_hotpath.h"
@@ -240,10 +241,19 @@ public:
     {
         for (auto& p : n_pts) { forw_pts.push_back(p); ids.push_back(-1); track_cnt.push_back(1); }
     }
-    // readImage without CLAHE (EQUALIZE == 0), rejectWithF and undistortedPoints (host side,
-    // not on the accelerated path).  `img` is ROW x COL, 8-bit, tightly packed.
-    void readImage(const uint8_t* img)
+    // EQUALIZE (feature_tracker.cpp:86-90): CLAHE(3.0, 8x8) on the device, inside push_image
+    void setEqualize(bool on) { check(lvi_tracker_set_equalize(t_.get(), on ? 1 : 0, 3.0, 8, 8), "lvi_tracker_set_equalize"); }
+    void setCamera(const lvi_mei_params& cam) { cam_ = cam; have_cam_ = true; }
+
+    std::vector<Point2f> cur_un_pts, pts_velocity;
+    std::map<int, Point2f> cur_un_pts_map, prev_un_pts_map;
+    double cur_time = 0.0, prev_time = 0.0;
+
+    // readImage without rejectWithF (findFundamentalMat RANSAC stays on the host).  `img` is ROW x COL,
+    // 8-bit, tightly packed.
+    void readImage(const uint8_t* img, double _cur_time = 0.0)
     {
+        cur_time = _cur_time;
         check(lvi_tracker_push_image(t_.get(), img, COL, ROW, COL), "lvi_tracker_push_image");   // forw_img = img (:94-101)
         forw_pts.clear();
         if (!cur_pts.empty()) {
@@ -276,6 +286,34 @@ public:
         }
         prev_pts = cur_pts;                                                                       // :200-204
         cur_pts = forw_pts;
+        if (have_cam_) undistortedPoints();                                                       // :205
+        prev_time = cur_time;
+    }
+    void undistortedPoints()                                    // :298-347, liftProjective on the device (f-3)
+    {
+        cur_un_pts.assign(cur_pts.size(), Point2f{0.f, 0.f});
+        cur_un_pts_map.clear();
+        if (!cur_pts.empty())
+            check(lvi_undistort_points(t_.get(), &cam_, &cur_pts[0].x, (int32_t)cur_pts.size(), &cur_un_pts[0].x), "lvi_undistort_points");
+        for (size_t i = 0; i < cur_pts.size(); i++) cur_un_pts_map.insert({ids[i], cur_un_pts[i]});
+        pts_velocity.clear();
+        if (!prev_un_pts_map.empty()) {
+            const double dt = cur_time - prev_time;
+            for (size_t i = 0; i < cur_un_pts.size(); i++) {
+                Point2f v{0.f, 0.f};
+                if (ids[i] != -1) {
+                    auto it = prev_un_pts_map.find(ids[i]);
+                    if (it != prev_un_pts_map.end()) {
+                        v.x = (float)((double)(cur_un_pts[i].x - it->second.x) / dt);
+                        v.y = (float)((double)(cur_un_pts[i].y - it->second.y) / dt);
+                    }
+                }
+                pts_velocity.push_back(v);
+            }
+        } else {
+            pts_velocity.assign(cur_pts.size(), Point2f{0.f, 0.f});
+        }
+        prev_un_pts_map = cur_un_pts_map;
     }
     bool updateID(unsigned int i)                               // :244-254
     {
@@ -285,6 +323,7 @@ public:
 private:
     TrackerHandle& t_;
     int ROW, COL, MAX_CNT, MIN_DIST;
+    lvi_mei_params cam_{}; bool have_cam_ = false;
 };
 
 }  // namespace lvi_host

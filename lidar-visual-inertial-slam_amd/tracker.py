@@ -66,6 +66,28 @@ class TrackerHotpath:
                        "lvi_good_features")
         return xy[:n.value].copy()
 
+    # ---- f-2 / f-3 ----------------------------------------------------------
+    def clahe(self, img, clip_limit=3.0, tiles=(8, 8)):
+        """cv::createCLAHE(clip_limit, tiles)->apply (feature_tracker.cpp:86-90)"""
+        img = _img(img)
+        h, w = img.shape
+        out = np.zeros((h, w), np.uint8)
+        self.lib.check(self.lib.dll.lvi_clahe(self._t, A._ptr(img), w, h, img.strides[0], float(clip_limit), int(tiles[0]), int(tiles[1]),
+                                              A._ptr(out), out.strides[0]), "lvi_clahe")
+        return out
+
+    def set_equalize(self, on, clip_limit=3.0, tiles=(8, 8)):
+        self.lib.check(self.lib.dll.lvi_tracker_set_equalize(self._t, 1 if on else 0, float(clip_limit), int(tiles[0]), int(tiles[1])),
+                       "lvi_tracker_set_equalize")
+
+    def undistort_points(self, cam, xy):
+        """cam: dict with xi,k1,k2,p1,p2,gamma1,gamma2,u0,v0 (MEI); returns liftProjective(x,y) / z as f32 pairs"""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        out = np.zeros_like(xy)
+        c = A.MeiParams(*[float(cam[k]) for k in ("xi", "k1", "k2", "p1", "p2", "gamma1", "gamma2", "u0", "v0")])
+        self.lib.check(self.lib.dll.lvi_undistort_points(self._t, C.byref(c), A._ptr(xy), len(xy), A._ptr(out)), "lvi_undistort_points")
+        return out
+
     # ---- staged form --------------------------------------------------------
     def push_image(self, img):
         img = _img(img)

@@ -356,6 +356,7 @@ struct lvi_tracker {
     bool have_lk = false;
     std::vector<uint8_t> mask; bool have_mask = false;
     std::vector<float> eig, gftt_xy; int gftt_n = 0, gftt_ncand = 0; bool have_gftt = false;
+    bool equalize = false; double clahe_clip = 3.0; int clahe_tx = 8, clahe_ty = 8;       // EQUALIZE (feature_tracker.cpp:86-90)
 };
 
 namespace {
@@ -374,6 +375,112 @@ void runLK(lvi_tracker* t, const std::vector<Image8>& prevPyr, int prevTop, cons
         scharr(prevPyr[level], dI);
         lkLevel(prevPyr[level], dI, nextPyr[level], prev_xy, next_xy, status, err, n, P.lk_win, level, maxLevel, maxCount, eps, P.lk_min_eig_threshold);
     }
+}
+
+// ---------------------------------------------------------------------------
+// f-2  cv::CLAHE::apply for CV_8UC1 (OpenCV 4.x imgproc/src/clahe.cpp: CLAHE_CalcLut_Body, CLAHE_Interpolation_Body;
+// source not in the reference tree, restated from the published algorithm — PARITY UNPINNED).
+//   * images whose size is not a multiple of the tile grid are extended to the right / bottom with REFLECT_101 for the
+//     histograms only;  * clipLimit = max(int(clip * tileArea / 256), 1);  * excess is redistributed evenly, the remainder
+//     one count every max(256 / residual, 1) bins;  * lut = saturate(cvRound(cumsum * (255.f / tileArea)));
+//   * output = bilinear blend of the four neighbouring tile LUTs, in f32, ((a*xa1 + b*xa)*ya1 + (c*xa1 + d*xa)*ya).
+// ---------------------------------------------------------------------------
+void clahe(const Image8& src, Image8& dst, double clipLimitD, int tilesX, int tilesY)
+{
+    const int histSize = 256;
+    const int W = src.w, H = src.h;
+    int extW = W, extH = H;
+    if (W % tilesX != 0 || H % tilesY != 0) { extW = W + (tilesX - (W % tilesX)); extH = H + (tilesY - (H % tilesY)); }   // copyMakeBorder(… tiles - (size % tiles) …)
+    const int tw = extW / tilesX, th = extH / tilesY;
+    const int tileSizeTotal = tw * th;
+    const float lutScale = static_cast<float>(histSize - 1) / tileSizeTotal;
+    int clipLimit = 0;
+    if (clipLimitD > 0.0) { clipLimit = static_cast<int>(clipLimitD * tileSizeTotal / histSize); clipLimit = std::max(clipLimit, 1); }
+    std::vector<uint8_t> lut((size_t)tilesX * tilesY * histSize);
+    for (int k = 0; k < tilesX * tilesY; k++) {
+        const int ty = k / tilesX, tx = k % tilesX;
+        int tileHist[256] = {0};
+        for (int y = ty * th; y < (ty + 1) * th; y++)
+            for (int x = tx * tw; x < (tx + 1) * tw; x++) {
+                // extended image = copyMakeBorder(src, 0, extH - H, 0, extW - W, BORDER_REFLECT_101)
+                const int sx = x < W ? x : reflect101(x, W), sy = y < H ? y : reflect101(y, H);
+                tileHist[src.at(sx, sy)]++;
+            }
+        if (clipLimit > 0) {
+            int clipped = 0;
+            for (int i = 0; i < histSize; ++i)
+                if (tileHist[i] > clipLimit) { clipped += tileHist[i] - clipLimit; tileHist[i] = clipLimit; }
+            int redistBatch = clipped / histSize;
+            int residual = clipped - redistBatch * histSize;
+            for (int i = 0; i < histSize; ++i) tileHist[i] += redistBatch;
+            if (residual != 0) {
+                int residualStep = std::max(histSize / residual, 1);
+                for (int i = 0; i < histSize && residual > 0; i += residualStep, residual--) tileHist[i]++;
+            }
+        }
+        int sum = 0;
+        uint8_t* tileLut = &lut[(size_t)k * histSize];
+        for (int i = 0; i < histSize; ++i) {
+            sum += tileHist[i];
+            const int v = cvRound(sum * lutScale);
+            tileLut[i] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
+    }
+    dst.w = W; dst.h = H; dst.px.resize((size_t)W * H);
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    for (int y = 0; y < H; y++) {
+        const float tyf = y * inv_th - 0.5f;
+        int ty1 = cvFloor(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        ty1 = std::max(ty1, 0); ty2 = std::min(ty2, tilesY - 1);
+        const uint8_t* lutPlane1 = &lut[(size_t)ty1 * tilesX * histSize];
+        const uint8_t* lutPlane2 = &lut[(size_t)ty2 * tilesX * histSize];
+        for (int x = 0; x < W; x++) {
+            const float txf = x * inv_tw - 0.5f;
+            int tx1 = cvFloor(txf), tx2 = tx1 + 1;
+            const float xa = txf - tx1, xa1 = 1.0f - xa;
+            tx1 = std::max(tx1, 0); tx2 = std::min(tx2, tilesX - 1);
+            const int srcVal = src.at(x, y);
+            const int ind1 = tx1 * histSize + srcVal, ind2 = tx2 * histSize + srcVal;
+            const float res = (lutPlane1[ind1] * xa1 + lutPlane1[ind2] * xa) * ya1 + (lutPlane2[ind1] * xa1 + lutPlane2[ind2] * xa) * ya;
+            const int v = cvRound(res);
+            dst.px[(size_t)y * W + x] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// f-3  CataCamera::liftProjective (CataCamera.cc:556-626) with the recursive distortion model (n = 8,
+// distortion() :766-783), all in double, followed by undistortedPoints' (b.x/b.z, b.y/b.z) → Point2f
+// (feature_tracker.cpp:306-309).
+// ---------------------------------------------------------------------------
+inline void mei_distortion(const lvi_mei_params& c, double pux, double puy, double& dux, double& duy)
+{
+    const double k1 = c.k1, k2 = c.k2, p1 = c.p1, p2 = c.p2;
+    const double mx2_u = pux * pux, my2_u = puy * puy, mxy_u = pux * puy;
+    const double rho2_u = mx2_u + my2_u;
+    const double rad_dist_u = k1 * rho2_u + k2 * rho2_u * rho2_u;
+    dux = pux * rad_dist_u + 2.0 * p1 * mxy_u + p2 * (rho2_u + 2.0 * mx2_u);
+    duy = puy * rad_dist_u + 2.0 * p2 * mxy_u + p1 * (rho2_u + 2.0 * my2_u);
+}
+inline void mei_undistort(const lvi_mei_params& c, float px, float py, float& ux, float& uy)
+{
+    const double inv_K11 = 1.0 / c.gamma1, inv_K13 = -c.u0 / c.gamma1, inv_K22 = 1.0 / c.gamma2, inv_K23 = -c.v0 / c.gamma2;   // :320-323
+    const bool noDistortion = c.k1 == 0.0 && c.k2 == 0.0 && c.p1 == 0.0 && c.p2 == 0.0;                                              // :307-317
+    const double mx_d = inv_K11 * (double)px + inv_K13, my_d = inv_K22 * (double)py + inv_K23;
+    double mx_u, my_u;
+    if (noDistortion) { mx_u = mx_d; my_u = my_d; }
+    else {
+        double dux, duy;
+        mei_distortion(c, mx_d, my_d, dux, duy);
+        mx_u = mx_d - dux; my_u = my_d - duy;
+        for (int i = 1; i < 8; ++i) { mei_distortion(c, mx_u, my_u, dux, duy); mx_u = mx_d - dux; my_u = my_d - duy; }
+    }
+    double bz;
+    const double xi = c.xi;
+    if (xi == 1.0) bz = (1.0 - mx_u * mx_u - my_u * my_u) / 2.0;
+    else { const double rho2_d = mx_u * mx_u + my_u * my_u; bz = 1.0 - xi * (rho2_d + 1.0) / (xi + std::sqrt(1.0 + (1.0 - xi * xi) * rho2_d)); }
+    ux = (float)(mx_u / bz); uy = (float)(my_u / bz);
 }
 
 bool load_image(Image8& im, const uint8_t* img, int w, int h, int stride)
@@ -415,9 +522,35 @@ int32_t lvi_tracker_push_image(lvi_tracker* t, const uint8_t* img, int32_t w, in
     if (w > t->P.max_width || h > t->P.max_height) return tfail(LVI_ERR_CAPACITY, "image exceeds capacity");
     if (t->have_forw) { t->curPyr.swap(t->forwPyr); t->curTop = t->forwTop; t->have_cur = true; }
     Image8 im; load_image(im, img, w, h, stride);
+    if (t->equalize) { Image8 eq; clahe(im, eq, t->clahe_clip, t->clahe_tx, t->clahe_ty); im = eq; }     // :86-90
     t->forwTop = buildPyramid(im, t->forwPyr, t->P.lk_win, t->P.lk_max_level);
     if (!t->have_forw) { t->curPyr = t->forwPyr; t->curTop = t->forwTop; t->have_cur = true; }   // prev = cur = forw = img (:94-97)
     t->have_forw = true; t->have_lk = false; t->have_gftt = false;
+    return LVI_OK;
+}
+int32_t lvi_clahe(lvi_tracker* t, const uint8_t* img, int32_t w, int32_t h, int32_t stride, double clip_limit, int32_t tiles_x, int32_t tiles_y,
+                  uint8_t* out, int32_t out_stride)
+{
+    if (!t || !img || !out || w <= 0 || h <= 0 || stride < w || out_stride < w) return tfail(LVI_ERR_INVALID_ARG, "bad image");
+    if (tiles_x < 1 || tiles_y < 1 || tiles_x > 64 || tiles_y > 64) return tfail(LVI_ERR_INVALID_ARG, "bad tile grid");
+    if (w > t->P.max_width || h > t->P.max_height) return tfail(LVI_ERR_CAPACITY, "image exceeds capacity");
+    Image8 im, eq; load_image(im, img, w, h, stride);
+    clahe(im, eq, clip_limit, tiles_x, tiles_y);
+    for (int y = 0; y < h; y++) std::memcpy(out + (size_t)y * out_stride, &eq.px[(size_t)y * w], w);
+    return LVI_OK;
+}
+int32_t lvi_tracker_set_equalize(lvi_tracker* t, int32_t on, double clip_limit, int32_t tiles_x, int32_t tiles_y)
+{
+    if (!t) return tfail(LVI_ERR_INVALID_ARG, "null handle");
+    if (on && (tiles_x < 1 || tiles_y < 1 || tiles_x > 64 || tiles_y > 64)) return tfail(LVI_ERR_INVALID_ARG, "bad tile grid");
+    t->equalize = on != 0; t->clahe_clip = clip_limit; t->clahe_tx = tiles_x; t->clahe_ty = tiles_y;
+    return LVI_OK;
+}
+int32_t lvi_undistort_points(lvi_tracker* t, const lvi_mei_params* cam, const float* xy, int32_t n, float* un_xy)
+{
+    if (!t || !cam || n < 0 || (n > 0 && (!xy || !un_xy))) return tfail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (n > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many points");
+    for (int i = 0; i < n; i++) mei_undistort(*cam, xy[2 * i], xy[2 * i + 1], un_xy[2 * i], un_xy[2 * i + 1]);
     return LVI_OK;
 }
 int32_t lvi_tracker_set_points(lvi_tracker* t, const float* cur_xy, int32_t n)

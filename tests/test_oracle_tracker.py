@@ -125,3 +125,116 @@ def test_gftt_min_distance_mask_and_threshold(pkg, T):
     with pytest.raises(pkg.LviError):
         T.good_features(img, 0, 0.0001, 0.5)
     big.close()
+
+
+# ----------------------------------------------------------------------------- f-2 CLAHE
+def _clahe_numpy(img, clip, tiles):
+    """independent vectorised restatement of cv::CLAHE::apply (8-bit): per-tile clipped histogram → LUT → f32 bilinear blend"""
+    tx_n, ty_n = tiles
+    H, W = img.shape
+    ext = img
+    if W % tx_n or H % ty_n:
+        ext = np.pad(img, ((0, ty_n - H % ty_n), (0, tx_n - W % tx_n)), mode="reflect")
+    th, tw = ext.shape[0] // ty_n, ext.shape[1] // tx_n
+    area = tw * th
+    scale = np.float32(255) / np.float32(area)
+    limit = max(int(clip * area / 256), 1) if clip > 0 else 0
+    lut = np.zeros((ty_n, tx_n, 256), np.uint8)
+    for ty in range(ty_n):
+        for tx in range(tx_n):
+            h = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if limit > 0:
+                clipped = int(np.maximum(h - limit, 0).sum())
+                h = np.minimum(h, limit)
+                batch, residual = divmod(clipped, 256)
+                h += batch
+                if residual:
+                    step = max(256 // residual, 1)
+                    idx = np.arange(0, 256, step)[:residual]
+                    h[idx] += 1
+            cdf = np.cumsum(h).astype(np.float32)
+            lut[ty, tx] = np.clip(np.rint(cdf * scale), 0, 255).astype(np.uint8)
+    ys, xs = np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32)
+    tyf = ys * (np.float32(1) / np.float32(th)) - np.float32(0.5)
+    txf = xs * (np.float32(1) / np.float32(tw)) - np.float32(0.5)
+    ty1, tx1 = np.floor(tyf).astype(int), np.floor(txf).astype(int)
+    ya, xa = (tyf - ty1.astype(np.float32)), (txf - tx1.astype(np.float32))
+    ya1, xa1 = np.float32(1) - ya, np.float32(1) - xa
+    ty2, tx2 = np.minimum(ty1 + 1, ty_n - 1), np.minimum(tx1 + 1, tx_n - 1)
+    ty1, tx1 = np.maximum(ty1, 0), np.maximum(tx1, 0)
+    v = img.astype(int)
+    f = lambda a, b: lut[a[:, None], b[None, :], v].astype(np.float32)
+    res = (f(ty1, tx1) * xa1[None, :] + f(ty1, tx2) * xa[None, :]) * ya1[:, None] + (f(ty2, tx1) * xa1[None, :] + f(ty2, tx2) * xa[None, :]) * ya[:, None]
+    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+
+
+def test_clahe_against_numpy(pkg, T):
+    rng = np.random.default_rng(8)
+    base = pkg.synth.texture_image(320, 240, seed=3) if hasattr(pkg.synth, "texture_image") else rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    for img, clip, tiles in ((base, 3.0, (8, 8)),
+                             (rng.integers(0, 256, (250, 333), dtype=np.uint8), 3.0, (8, 8)),       # not a multiple of the grid → REFLECT_101 extension
+                             (rng.integers(100, 140, (96, 128), dtype=np.uint8), 2.0, (4, 3)),      # narrow histogram → heavy clipping + residual path
+                             (rng.integers(0, 256, (64, 64), dtype=np.uint8), 0.0, (2, 2))):        # clip 0 = plain tile equalisation
+        got = T.clahe(img, clip, tiles)
+        np.testing.assert_array_equal(got, _clahe_numpy(img, clip, tiles))
+
+
+def test_clahe_periodic_image_is_a_single_lut(pkg, T):
+    """identical tiles → identical LUTs → the blend returns lut[src] exactly: equalisation with the clip-limited CDF"""
+    rng = np.random.default_rng(2)
+    tile = rng.integers(0, 256, (30, 40), dtype=np.uint8)
+    img = np.tile(tile, (8, 8))
+    got = T.clahe(img, 3.0, (8, 8))
+    h = np.bincount(tile.ravel(), minlength=256)
+    limit = max(int(3.0 * tile.size / 256), 1)
+    clipped = int(np.maximum(h - limit, 0).sum()); h = np.minimum(h, limit) + clipped // 256
+    res = clipped % 256
+    if res:
+        h[np.arange(0, 256, max(256 // res, 1))[:res]] += 1
+    lut = np.clip(np.rint(np.cumsum(h).astype(np.float32) * (np.float32(255) / np.float32(tile.size))), 0, 255).astype(np.uint8)
+    np.testing.assert_array_equal(got, lut[img])
+    # staged form: push_image equalises before the pyramid is built
+    T.set_equalize(True, 3.0, (8, 8))
+    T.push_image(img)
+    l1 = T.debug_get(pkg._abi.TDBG_PYRAMID_L1, np.uint8).reshape(120, 160)
+    np.testing.assert_array_equal(l1, _pyrdown_numpy(lut[img]))
+    T.set_equalize(False)
+    T.push_image(img)
+    np.testing.assert_array_equal(T.debug_get(pkg._abi.TDBG_PYRAMID_L1, np.uint8).reshape(120, 160), _pyrdown_numpy(img))
+
+
+# ----------------------------------------------------------------------------- f-3 MEI undistortion
+MEI = dict(xi=1.9926618269451453, k1=-0.0399258932468764, k2=0.15160828121223818, p1=0.00017756967825777937, p2=-0.0011531239076798612,
+           gamma1=669.8940458885896, gamma2=669.1450614220616, u0=377.9459252967363, v0=279.63655686698144)
+
+
+def _mei_project(c, P):
+    """CataCamera::spaceToPlane in float64 (the inverse of what is tested): unit-sphere + xi, distortion, K"""
+    P = P / np.linalg.norm(P, axis=1, keepdims=True)
+    z = P[:, 2] + c["xi"]
+    mx, my = P[:, 0] / z, P[:, 1] / z
+    r2 = mx * mx + my * my
+    rad = c["k1"] * r2 + c["k2"] * r2 * r2
+    dx = mx * rad + 2 * c["p1"] * mx * my + c["p2"] * (r2 + 2 * mx * mx)
+    dy = my * rad + 2 * c["p2"] * mx * my + c["p1"] * (r2 + 2 * my * my)
+    return np.stack([c["gamma1"] * (mx + dx) + c["u0"], c["gamma2"] * (my + dy) + c["v0"]], axis=1)
+
+
+def test_mei_undistortion_round_trip(pkg, T):
+    rng = np.random.default_rng(4)
+    # within 230 px of the principal point the lifted ray looks forward (b.z > 0), so (un, 1) keeps its direction
+    xy = np.stack([rng.uniform(MEI["u0"] - 160, MEI["u0"] + 160, 300), rng.uniform(MEI["v0"] - 160, MEI["v0"] + 160, 300)], axis=1).astype(np.float32)
+    un = T.undistort_points(MEI, xy).astype(np.float64)
+    # (un.x, un.y, 1) is the viewing ray: projecting it again must land on the pixel (8 fixed-point iterations → ~1e-6 px here)
+    back = _mei_project(MEI, np.concatenate([un, np.ones((len(un), 1))], axis=1))
+    assert np.abs(back - xy).max() < 2e-3
+    # pinhole special case: no distortion, xi = 0 → (x - u0) / gamma
+    pin = dict(MEI, xi=0.0, k1=0.0, k2=0.0, p1=0.0, p2=0.0)
+    un = T.undistort_points(pin, xy)
+    want = np.stack([(xy[:, 0].astype(np.float64) - pin["u0"]) / pin["gamma1"], (xy[:, 1].astype(np.float64) - pin["v0"]) / pin["gamma2"]], axis=1)
+    assert np.abs(un - want).max() < 1e-6
+    # xi == 1 branch (:610-613)
+    un1 = T.undistort_points(dict(pin, xi=1.0), xy).astype(np.float64)
+    back = _mei_project(dict(pin, xi=1.0), np.concatenate([un1, np.ones((len(un1), 1))], axis=1))
+    assert np.abs(back - xy).max() < 2e-3
+    assert len(T.undistort_points(MEI, np.zeros((0, 2), np.float32))) == 0
