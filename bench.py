@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--kf-n-raw", type=int, default=30001)
     ap.add_argument("--map-points", type=int, default=5_000_000)
     ap.add_argument("--frozen-map", action="store_true", help="reuse the DS map/index across scans (not the headline)")
+    ap.add_argument("--map-source", choices=["resident", "assemble"], default="resident",
+                    help="resident: the raw local map sits in HBM as one cloud (headline); assemble: it is fused per scan from the "
+                         "device-resident keyframe store (SURVEY f-4: what a node does instead of uploading 78 MB per scan)")
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--pool", type=int, default=8, help="distinct scans per rank, cycled")
     ap.add_argument("--inflight", type=int, default=4,
@@ -75,7 +78,9 @@ def main():
     hip = pkg.load_hip()                      # raises when the HIP library is missing: no fallback
 
     P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=args.map_points + 65536,
-             icp_max_iters=args.icp_iters, icp_disable_break=1)
+             icp_max_iters=args.icp_iters, icp_disable_break=1,
+             max_keyframes=(args.keyframes + 8) if args.map_source == "assemble" else 0,
+             max_keyframe_points=(args.map_points + 200000) if args.map_source == "assemble" else 0)
     B = max(1, args.inflight)
     hs = [pkg.LidarHotpath(hip, device=local_rank, **P) for _ in range(B)]
     g = hs[0]
@@ -98,10 +103,26 @@ def main():
         dist.broadcast(d_mc, 0)
         dist.broadcast(d_ms, 0)
     torch.cuda.synchronize()
-    for h in hs:
-        h.map_upload_device(d_mc.data_ptr(), nc, d_ms.data_ptr(), ns)
-        h.map_build()
-        h.sync()
+    keys = None
+    if args.map_source == "assemble":
+        # SURVEY f-4: the local map is not handed over as one raw cloud but fused on the device, per scan, from the
+        # keyframe store (here: the same points cut into --keyframes pieces, stored with the identity pose, so the
+        # fused map — and therefore every result — is bit-identical to the resident-map run)
+        hc, hsurf = d_mc.cpu().numpy(), d_ms.cpu().numpy()
+        K = max(1, args.keyframes)
+        cb = np.linspace(0, nc, K + 1).astype(np.int64); sb = np.linspace(0, ns, K + 1).astype(np.int64)
+        for h in hs:
+            for k in range(K):
+                h.keyframe_add(hc[cb[k]:cb[k + 1]], hsurf[sb[k]:sb[k + 1]], np.zeros(6, np.float32))
+        keys = np.arange(K, dtype=np.int32)
+        for h in hs:
+            h.map_assemble(keys)
+            h.sync()
+    else:
+        for h in hs:
+            h.map_upload_device(d_mc.data_ptr(), nc, d_ms.data_ptr(), ns)
+            h.map_build()
+            h.sync()
     cnt_map = g.counts()
 
     # ---------------------------------------------------------------- scan pool of this rank, resident in HBM
@@ -134,7 +155,10 @@ def main():
                 h.scan_replay_enqueue(d_scans[k].data_ptr(), args.n_raw, guesses[k], d_rec[i * B + b].data_ptr(), rebuild_map=not args.frozen_map)
             else:
                 if not args.frozen_map:
-                    h.map_build()                                         # own stream: overlaps the scan-side stages
+                    if keys is not None:
+                        h.map_assemble(keys)                              # fuse the keyframes, then the build (f-4)
+                    else:
+                        h.map_build()                                     # own stream: overlaps the scan-side stages
                 h.scan_upload_device(d_scans[k].data_ptr(), args.n_raw)   # D2D, 2 MB
                 h.scan_organize(); h.scan_extract(); h.scan_downsample()
                 h.scan_match_async(guesses[k], d_rec[i * B + b].data_ptr())
@@ -236,7 +260,7 @@ def main():
                     if not args.frozen_map else "lidar_odometry scan-to-map with a frozen downsampled map (DS + index reused)",
                     n_raw=args.n_raw, map_raw_points=nc + ns, map_ds_points=cnt_map["map_corner_ds"] + cnt_map["map_surf_ds"],
                     scan_features=dict(corner=cnt["corner"], surf=cnt["surf"], corner_ds=cnt["corner_ds"], surf_ds=cnt["surf_ds"]),
-                    icp_iters=args.icp_iters, scans_in_flight_per_gpu=B, scans_per_step=world * B, enqueue=args.enqueue,
+                    icp_iters=args.icp_iters, map_source=args.map_source, scans_in_flight_per_gpu=B, scans_per_step=world * B, enqueue=args.enqueue,
                     sharding="independent scans sharded across ranks (B in flight per rank), RCCL all_gather of pose records per step"),
         roofline=roofline, roofline_streaming_kernel=roofline_bw,
         results_ok=ok, pose_err_vs_truth=dict(trans_m=err_t, rot_rad=err_r),

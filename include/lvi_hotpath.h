@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LVI_ABI_VERSION 2
+#define LVI_ABI_VERSION 3
 
 /* ---- status codes -------------------------------------------------------- */
 #define LVI_OK                        0
@@ -89,6 +89,9 @@ typedef struct lvi_lidar_params {
     /* realisation of the voxel grids: 0 = auto (per batch, from the previous batch's grid size), 1 = sorted, 2 = binned.
      * Same output bits either way; only the HIP backend reads it. */
     int32_t voxel_mode;
+    /* f-4: device-resident keyframe store (cornerCloudKeyFrames / surfCloudKeyFrames); 0 keyframes = no store */
+    int32_t max_keyframes;              /* default 1024 */
+    int32_t max_keyframe_points;        /* corner + surf points of all stored keyframes together, default 2^22 */
 } lvi_lidar_params;
 
 /* CloudInfo.msg:4-8 arrays + cloud_deskewed, as plain caller-owned arrays.
@@ -197,6 +200,22 @@ int32_t lvi_transform_cloud(lvi_lidar *h, const lvi_pt *in, int32_t n, const flo
  * upload → run stages on the handle's stream → fetch.  Used by the replay
  * harness and bench so that inputs are resident in HBM when timing starts. */
 int32_t lvi_scan_upload(lvi_lidar *h, const lvi_livox_pt *pts, int32_t n_raw);   /* H2D only */
+/* ---- f-4: keyframe store and map assembly on the device --------------------------------------------------------------
+ * saveKeyFramesAndFactor pushes the scan's DS clouds into cornerCloudKeyFrames / surfCloudKeyFrames with the optimised
+ * pose (mapOptimization.cpp:1594-1599); extractCloud (:931-957) transforms every selected keyframe by its pose
+ * (transformPointCloud :347-366) and concatenates them into laserCloud{Corner,Surf}FromMap.  With the clouds resident
+ * on the device the per-scan upload of the raw local map (16 B x 5 M points) disappears: the node sends the ordered
+ * list of selected keyframe indices (extractNearby's kd-tree radius search over the key POSES stays in the node).
+ * Poses are [roll, pitch, yaw, x, y, z] as transformTobeMapped / PointTypePose. */
+int32_t lvi_keyframe_add(lvi_lidar *h, const lvi_pt *corner, int32_t nc, const lvi_pt *surf, int32_t ns, const float pose[6], int32_t *index_out);
+/* the same from the clouds the last lvi_scan_downsample / lvi_scan_to_map left on the device (laserCloud{Corner,Surf}LastDS) */
+int32_t lvi_keyframe_add_current(lvi_lidar *h, const float pose[6], int32_t *index_out);
+int32_t lvi_keyframe_set_pose(lvi_lidar *h, int32_t index, const float pose[6]);      /* correctPoses :1650-1660 */
+int32_t lvi_keyframe_count(lvi_lidar *h, int32_t *n_keyframes, int32_t *n_points);
+int32_t lvi_keyframes_clear(lvi_lidar *h);
+/* extractCloud for the keys in the given order (duplicates allowed, as the reference's list may hold them) followed by the
+ * two map VoxelGrids and the index build: equivalent to lvi_map_set(fused corner, fused surf). */
+int32_t lvi_map_assemble(lvi_lidar *h, const int32_t *key_indices, int32_t n_keys);
 int32_t lvi_scan_organize(lvi_lidar *h);                                         /* a-0 (+ f-1 when a deskew table is set) */
 /* f-1: rotation table for the NEXT lvi_scan_organize calls (copied; NULL or imu_available == 0 switches deskew off). */
 int32_t lvi_scan_set_deskew(lvi_lidar *h, const lvi_deskew_info *info);
@@ -245,6 +264,8 @@ enum {
     LVI_DBG_ICP_POSE_TRACE = 10,  /* f32[(iters+1)*6] transformTobeMapped before iteration k (and after the last) */
     LVI_DBG_ICP_CYCLES     = 12,  /* i64[16] [hip only] ([8..12]: solve kernel: partial sums, combine, solve, pose, total) shader cycles of workgroup 0 of the last residual launch: pose load, KNN scan,
                                      top-5 merge, residual math, row reduction, total; [6] = candidates scanned by lane 0 */
+    LVI_DBG_MAP_CORNER_RAW = 13,  /* lvi_pt[] laserCloudCornerFromMap as uploaded / assembled */
+    LVI_DBG_MAP_SURF_RAW   = 14,  /* lvi_pt[] laserCloudSurfFromMap */
     LVI_DBG_FEAT_CYCLES    = 11   /* i64[8] [hip only] shader cycles of ring 0's sector kernel by phase: load, compact, rank, walk,
                                      fixed-point set-up, fixed-point rounds, number of rounds, apply+store */
 };

@@ -27,6 +27,8 @@ LVI_ICP_MAX_ITERS = 64
 DBG_CURVATURE, DBG_PICKED_OCCL, DBG_LABEL, DBG_PICKED_FINAL, DBG_CORNER_INDEX = 1, 2, 3, 4, 5
 DBG_VOXEL_KEYS, DBG_VOXEL_CELLS, DBG_VOXEL_COUNTS, DBG_ICP_JTJ, DBG_ICP_POSE_TRACE = 6, 7, 8, 9, 10
 DBG_FEAT_CYCLES = 11
+DBG_MAP_CORNER_RAW = 13
+DBG_MAP_SURF_RAW = 14
 DBG_ICP_CYCLES = 12
 TDBG_PYRAMID_L1, TDBG_PYRAMID_L2, TDBG_PYRAMID_L3, TDBG_MINEIG, TDBG_GFTT_NCAND = 1, 2, 3, 4, 5
 
@@ -44,7 +46,8 @@ class LidarParams(C.Structure):
                 ("odometrySurfLeafSize", C.c_float), ("mappingCornerLeafSize", C.c_float), ("mappingSurfLeafSize", C.c_float),
                 ("z_tollerance", C.c_float), ("rotation_tollerance", C.c_float), ("imuRPYWeight", C.c_float),
                 ("numberOfCores", C.c_int32), ("icp_max_iters", C.c_int32), ("icp_disable_break", C.c_int32),
-                ("max_raw_points", C.c_int32), ("max_map_points", C.c_int32), ("voxel_mode", C.c_int32)]
+                ("max_raw_points", C.c_int32), ("max_map_points", C.c_int32), ("voxel_mode", C.c_int32),
+                ("max_keyframes", C.c_int32), ("max_keyframe_points", C.c_int32)]
 
 
 class ScanInfo(C.Structure):
@@ -110,6 +113,12 @@ SIGNATURES = {
     "lvi_scan_upload": (_i32, [_vp, _vp, _i32]),
     "lvi_scan_organize": (_i32, [_vp]),
     "lvi_scan_set_deskew": (_i32, [_vp, _vp]),
+    "lvi_keyframe_add": (_i32, [_vp, _vp, _i32, _vp, _i32, _P(C.c_float), _P(_i32)]),
+    "lvi_keyframe_add_current": (_i32, [_vp, _P(C.c_float), _P(_i32)]),
+    "lvi_keyframe_set_pose": (_i32, [_vp, _i32, _P(C.c_float)]),
+    "lvi_keyframe_count": (_i32, [_vp, _P(_i32), _P(_i32)]),
+    "lvi_keyframes_clear": (_i32, [_vp]),
+    "lvi_map_assemble": (_i32, [_vp, _P(_i32), _i32]),
     "lvi_organize_scan_deskew": (_i32, [_vp, _vp, _i32, _vp, _P(ScanInfo)]),
     "lvi_scan_extract": (_i32, [_vp]),
     "lvi_scan_downsample": (_i32, [_vp]),

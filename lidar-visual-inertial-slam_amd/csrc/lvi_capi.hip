@@ -166,6 +166,7 @@ void lvi_lidar_params_default(lvi_lidar_params* p)
     p->numberOfCores = 8;
     p->icp_max_iters = 20; p->icp_disable_break = 0;
     p->max_raw_points = 131072; p->max_map_points = 1 << 20; p->voxel_mode = 0;
+    p->max_keyframes = 1024; p->max_keyframe_points = 1 << 22;
 }
 
 int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** out)
@@ -205,6 +206,7 @@ void lvi_lidar_destroy(lvi_lidar* h)
     h->d.voxRing.release(); h->d.voxScan.release(); h->d.voxMap.release(); h->d.voxGen.release();
     h->d.arena.release();
     if (h->d.h_icp) (void)hipHostFree(h->d.h_icp);
+    if (h->d.h_kfSeg) (void)hipHostFree(h->d.h_kfSeg);
     if (h->d.graphExec) (void)hipGraphExecDestroy(h->d.graphExec);
     if (h->d.ctx.stream) (void)hipStreamDestroy(h->d.ctx.stream);
     if (h->d.ctx2.stream) (void)hipStreamDestroy(h->d.ctx2.stream);
@@ -442,6 +444,87 @@ int32_t lvi_get_pose_record(lvi_lidar* h, lvi_pose_record* out)
 }
 
 // ---- one-call forms ------------------------------------------------------------------------------
+// ---- f-4 -------------------------------------------------------------------------------------------------
+static int32_t kf_reserve(lvi_lidar* h, int nc, int ns)
+{
+    LidarDev& d = h->d;
+    if ((int)d.kf_pose.size() >= d.P.max_keyframes || (long long)d.kf_pool_used + nc + ns > (long long)d.kf_pool_cap)
+        return fail(LVI_ERR_CAPACITY, "keyframe store full");
+    return LVI_OK;
+}
+static int32_t kf_commit(lvi_lidar* h, int nc, int ns, const float pose[6], int32_t* index_out)
+{
+    LidarDev& d = h->d;
+    d.kf_off_c.push_back(d.kf_pool_used); d.kf_n_c.push_back(nc);
+    d.kf_off_s.push_back(d.kf_pool_used + nc); d.kf_n_s.push_back(ns);
+    d.kf_pool_used += nc + ns;
+    d.kf_pose.push_back({pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]});
+    if (index_out) *index_out = (int32_t)d.kf_pose.size() - 1;
+    return LVI_OK;
+}
+int32_t lvi_keyframe_add(lvi_lidar* h, const lvi_pt* corner, int32_t nc, const lvi_pt* surf, int32_t ns, const float pose[6], int32_t* index_out)
+{
+    if (!h || nc < 0 || ns < 0 || (nc > 0 && !corner) || (ns > 0 && !surf) || !pose) return fail(LVI_ERR_INVALID_ARG, "bad keyframe arguments");
+    int32_t st = kf_reserve(h, nc, ns); if (st) return st;
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        h2d(d, d.kfPool + d.kf_pool_used, corner, (size_t)nc);
+        h2d(d, d.kfPool + d.kf_pool_used + nc, surf, (size_t)ns);
+        sync(d);
+        return kf_commit(h, nc, ns, pose, index_out);
+    });
+}
+int32_t lvi_keyframe_add_current(lvi_lidar* h, const float pose[6], int32_t* index_out)
+{
+    if (!h || !pose) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        int nq[3] = {0, 0, 0};
+        d2h(d, nq, d.voxScan.d_nout, 3); sync(d);                    // a keyframe is saved every ~1 m of motion: one 12-byte read
+        int32_t st = kf_reserve(h, nq[0], nq[1]); if (st) return st;
+        if (nq[0]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used, d.cornerDS, sizeof(lvi_pt) * (size_t)nq[0], hipMemcpyDeviceToDevice, d.ctx.stream));
+        if (nq[1]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used + nq[0], d.surfDS, sizeof(lvi_pt) * (size_t)nq[1], hipMemcpyDeviceToDevice, d.ctx.stream));
+        return kf_commit(h, nq[0], nq[1], pose, index_out);
+    });
+}
+int32_t lvi_keyframe_set_pose(lvi_lidar* h, int32_t index, const float pose[6])
+{
+    if (!h || !pose || index < 0 || index >= (int32_t)h->d.kf_pose.size()) return fail(LVI_ERR_INVALID_ARG, "bad keyframe index");
+    for (int k = 0; k < 6; k++) h->d.kf_pose[index][k] = pose[k];
+    return LVI_OK;
+}
+int32_t lvi_keyframe_count(lvi_lidar* h, int32_t* n_keyframes, int32_t* n_points)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    if (n_keyframes) *n_keyframes = (int32_t)h->d.kf_pose.size();
+    if (n_points) *n_points = h->d.kf_pool_used;
+    return LVI_OK;
+}
+int32_t lvi_keyframes_clear(lvi_lidar* h)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        join_map(d); sync(d);                                        // an assembly in flight still reads the pool
+        d.kf_off_c.clear(); d.kf_n_c.clear(); d.kf_off_s.clear(); d.kf_n_s.clear(); d.kf_pose.clear(); d.kf_pool_used = 0;
+        return LVI_OK;
+    });
+}
+int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys)
+{
+    if (!h || n_keys < 0 || (n_keys > 0 && !key_indices)) return fail(LVI_ERR_INVALID_ARG, "bad key list");
+    if (2 * n_keys > h->d.kf_seg_cap) return fail(LVI_ERR_CAPACITY, "key list longer than the assembly table");
+    long long tc = 0, ts = 0;
+    for (int i = 0; i < n_keys; i++) {
+        const int k = key_indices[i];
+        if (k < 0 || k >= (int)h->d.kf_pose.size()) return fail(LVI_ERR_INVALID_ARG, "key index out of range");
+        tc += h->d.kf_n_c[k]; ts += h->d.kf_n_s[k];
+    }
+    if (tc > h->d.map_cap || ts > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    return guarded(h, [&]() -> int32_t { stage_map_assemble(h->d, key_indices, n_keys); return LVI_OK; });
+}
+
 int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
@@ -591,6 +674,13 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
                 if (!need_feat()) return fail(LVI_ERR_STATE, "stage not run");
                 const int n = read_int(d, d.d_ncorner);
                 std::vector<int32_t> v(n); d2h(d, v.data(), d.corner_idx, (size_t)n); sync(d);
+                return dbg_out(v, 0, dst, cap, n_bytes);
+            }
+            case LVI_DBG_MAP_CORNER_RAW: case LVI_DBG_MAP_SURF_RAW: {
+                if (!d.have_map_raw) return fail(LVI_ERR_STATE, "no map");
+                const bool sf = what == LVI_DBG_MAP_SURF_RAW;
+                const int n = sf ? d.n_map_surf : d.n_map_corner;
+                std::vector<lvi_pt> v((size_t)n); d2h(d, v.data(), sf ? d.mapSurfRaw : d.mapCornerRaw, (size_t)n); sync(d);
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
             case LVI_DBG_ICP_CYCLES: {

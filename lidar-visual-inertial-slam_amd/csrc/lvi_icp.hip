@@ -946,6 +946,53 @@ void stage_map_build(LidarDev& d)
     d.map_pending = true;
 }
 
+// f-4.  extractCloud's fuse loop (mapOptimization.cpp:931-957): every listed keyframe cloud through
+// transformPointCloud (:347-366) with the key's pose, written at its place in laserCloud{Corner,Surf}FromMap.
+// The 3x4 matrices come from the host (pcl::getTransformation evaluated with libm, as in the reference), so the
+// fused clouds are bit-identical to the CPU's; blockIdx.y = piece, grid-stride over its points.
+__global__ __launch_bounds__(256) void kf_assemble_kernel(const LidarDev::KfSeg* __restrict__ segs, const lvi_pt* __restrict__ pool,
+                                                          lvi_pt* __restrict__ outC, lvi_pt* __restrict__ outS)
+{
+    const LidarDev::KfSeg sg = segs[blockIdx.y];
+    const lvi_pt* __restrict__ in = pool + sg.in_off;
+    lvi_pt* __restrict__ out = (sg.which ? outS : outC) + sg.out_off;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < sg.n; i += gridDim.x * 256) out[i] = to_map(sg.A, in[i]);
+}
+
+void stage_map_assemble(LidarDev& d, const int32_t* keys, int n_keys)
+{
+    join_map(d);                                    // the previous build may still read the raw buffers
+    // h_kfSeg is reused by every call: the previous assembly's H2D copy must have been consumed
+    LVI_HIP(hipStreamSynchronize(d.ctx.stream));
+    int oc = 0, os = 0, nseg = 0, maxn = 1;
+    for (int i = 0; i < n_keys; i++) {
+        const int k = keys[i];
+        const float* T = d.kf_pose[k].data();
+        // pcl::getTransformation(x, y, z, roll, pitch, yaw), transformIn = [roll, pitch, yaw, x, y, z] (:404-407)
+        const float A = std::cos(T[2]), B = std::sin(T[2]), C = std::cos(T[1]), D = std::sin(T[1]), E = std::cos(T[0]), F = std::sin(T[0]), DE = D * E, DF = D * F;
+        const float M[12] = {A * C, A * DF - B * E, B * F + A * DE, T[3],  B * C, A * E + B * DF, B * DE - A * F, T[4],  -D, C * F, C * E, T[5]};
+        for (int which = 0; which < 2; which++) {
+            LidarDev::KfSeg& sg = d.h_kfSeg[nseg++];
+            sg.which = which;
+            sg.in_off = which ? d.kf_off_s[k] : d.kf_off_c[k];
+            sg.n = which ? d.kf_n_s[k] : d.kf_n_c[k];
+            sg.out_off = which ? os : oc;
+            for (int q = 0; q < 12; q++) sg.A[q] = M[q];
+            (which ? os : oc) += sg.n;
+            maxn = std::max(maxn, sg.n);
+        }
+    }
+    if (nseg) {
+        LVI_HIP(hipMemcpyAsync(d.d_kfSeg, d.h_kfSeg, sizeof(LidarDev::KfSeg) * (size_t)nseg, hipMemcpyHostToDevice, d.ctx.stream));
+        const dim3 grid(std::min(div_up(maxn, 256), 64), nseg);
+        LVI_LAUNCH(d.ctx, "kf_assemble", 32.0 * ((double)oc + os), hipLaunchKernelGGL(kf_assemble_kernel, grid, dim3(256), 0, d.ctx.stream,
+                                                                                     d.d_kfSeg, d.kfPool, d.mapCornerRaw, d.mapSurfRaw));
+    }
+    d.n_map_corner = oc; d.n_map_surf = os; d.have_map_raw = true;
+    stage_map_build(d);
+    d.have_map = true;
+}
+
 void set_pose_init(LidarDev& d, const float p[6])
 {
     hipLaunchKernelGGL(set_pose_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, d.d_pose_init, p[0], p[1], p[2], p[3], p[4], p[5]);

@@ -1,6 +1,8 @@
 // Device-resident state of one lidar handle and the stage launchers (implemented in
 // lvi_scan.hip and lvi_icp.hip; lvi_capi.hip wires them to the C-ABI).
 #pragma once
+#include <array>
+
 #include "lvi_voxel.hpp"
 
 namespace lvi {
@@ -54,6 +56,13 @@ struct LidarDev {
 
     // ---- a-0
     lvi_livox_pt* raw = nullptr; int n_raw = 0;            // after dropping the last point
+    // ---- f-4 (keyframe store): clouds in the sensor frame, packed in one pool; tables on the host
+    struct KfSeg { int in_off, n, out_off, which; float A[12]; };              // one (keyframe, corner|surf) piece of an assembly
+    lvi_pt* kfPool = nullptr; int kf_pool_cap = 0, kf_pool_used = 0;
+    std::vector<int> kf_off_c, kf_n_c, kf_off_s, kf_n_s;
+    std::vector<std::array<float, 6>> kf_pose;
+    KfSeg* d_kfSeg = nullptr; KfSeg* h_kfSeg = nullptr;                        // [2 * max_assemble_keys] device / pinned host
+    int kf_seg_cap = 0;
     // ---- f-1 (IMU deskew): imuDeskewInfo's table, set by lvi_scan_set_deskew
     bool dk_on = false; int dk_cur = 0; double dk_t0 = 0.0;
     double* d_dk = nullptr;                                // [4][LVI_DESKEW_MAX_IMU] imuTime, imuRotX, imuRotY, imuRotZ
@@ -103,6 +112,7 @@ struct LidarDev {
 
 // lvi_scan.hip
 void lidar_allocate(LidarDev& d);
+void stage_map_assemble(LidarDev& d, const int32_t* keys, int n_keys);      // f-4: fuse the keyframes into the raw map buffers, then stage_map_build
 void stage_organize(LidarDev& d);
 void stage_extract(LidarDev& d);
 void stage_downsample(LidarDev& d);

@@ -622,6 +622,8 @@ void layout(AR& ar, LidarDev& d)
     d.genIn = ar.template alloc<lvi_pt>(gen_cap); d.genOut = ar.template alloc<lvi_pt>(gen_cap);
     d.voxGen.allocate(ar, 1, gen_cap, false);
     d.genKeysDbg = ar.template alloc<unsigned>(gen_cap);
+    d.kfPool = ar.template alloc<lvi_pt>((size_t)std::max(d.kf_pool_cap, 1));
+    d.d_kfSeg = ar.template alloc<LidarDev::KfSeg>((size_t)std::max(d.kf_seg_cap, 1));
     d.icp = ar.template alloc<IcpState>(1);
     d.d_pose_init = ar.template alloc<float>(8);
     d.icpPartial = ar.template alloc<double>((size_t)d.nblk_icp * 28);
@@ -652,6 +654,8 @@ void lidar_allocate(LidarDev& d)
     d.ext_cap = (int)std::max<long long>(std::min<long long>(d.raw_cap, full), 64);
     d.map_cap = std::max(d.P.max_map_points, 64);
     d.nblk_org = div_up(d.raw_cap, ORG_TILE);
+    d.kf_pool_cap = d.P.max_keyframes > 0 ? std::max(d.P.max_keyframe_points, 0) : 0;
+    d.kf_seg_cap = 2 * std::max(d.P.max_keyframes, 0) + 2048;       // an assembly may list a key more than once
     d.max_cells = 1 << 24;
     d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / 8);      // 8 lanes per query (KNN_G)
     ArenaSizer sz;
@@ -663,6 +667,7 @@ void lidar_allocate(LidarDev& d)
     LVI_HIP(hipMemcpyAsync(d.d_fresh, &one, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
     LVI_HIP(hipMemcpyAsync(d.d_dk_first, &int_max, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
     LVI_HIP(hipHostMalloc((void**)&d.h_icp, sizeof(IcpState), hipHostMallocDefault));
+    LVI_HIP(hipHostMalloc((void**)&d.h_kfSeg, sizeof(LidarDev::KfSeg) * (size_t)std::max(d.kf_seg_cap, 1), hipHostMallocDefault));
     // static segment tables of the voxel plans
     std::vector<VoxSegStatic> st(std::max(d.P.N_SCAN, 2));
     for (int r = 0; r < d.P.N_SCAN; r++) st[r] = VoxSegStatic{d.pts, d.surfmask, d.surf, d.P.odometrySurfLeafSize};

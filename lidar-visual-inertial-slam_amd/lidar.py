@@ -153,6 +153,34 @@ class LidarHotpath:
         self.lib.check(self.lib.dll.lvi_scan_replay_enqueue(self._h, C.c_void_p(int(d_scan_ptr)), int(n_raw), pose_c,
                                                             C.c_void_p(int(d_record_ptr)), 1 if rebuild_map else 0), "lvi_scan_replay_enqueue")
 
+    # ---- f-4: keyframe store / map assembly ---------------------------------
+    def keyframe_add(self, corner, surf, pose):
+        c, s = A.as_pts(corner), A.as_pts(surf)
+        pose_c = (C.c_float * 6)(*[float(v) for v in pose]); idx = C.c_int32(-1)
+        self.lib.check(self.lib.dll.lvi_keyframe_add(self._h, A._ptr(c), len(c), A._ptr(s), len(s), pose_c, C.byref(idx)), "lvi_keyframe_add")
+        return idx.value
+
+    def keyframe_add_current(self, pose):
+        pose_c = (C.c_float * 6)(*[float(v) for v in pose]); idx = C.c_int32(-1)
+        self.lib.check(self.lib.dll.lvi_keyframe_add_current(self._h, pose_c, C.byref(idx)), "lvi_keyframe_add_current")
+        return idx.value
+
+    def keyframe_set_pose(self, index, pose):
+        pose_c = (C.c_float * 6)(*[float(v) for v in pose])
+        self.lib.check(self.lib.dll.lvi_keyframe_set_pose(self._h, int(index), pose_c), "lvi_keyframe_set_pose")
+
+    def keyframe_count(self):
+        n, p = C.c_int32(0), C.c_int32(0)
+        self.lib.check(self.lib.dll.lvi_keyframe_count(self._h, C.byref(n), C.byref(p)), "lvi_keyframe_count")
+        return n.value, p.value
+
+    def keyframes_clear(self):
+        self.lib.check(self.lib.dll.lvi_keyframes_clear(self._h), "lvi_keyframes_clear")
+
+    def map_assemble(self, key_indices):
+        k = np.ascontiguousarray(key_indices, np.int32)
+        self.lib.check(self.lib.dll.lvi_map_assemble(self._h, k.ctypes.data_as(C.POINTER(C.c_int32)), len(k)), "lvi_map_assemble")
+
     def scan_organize(self):
         self.lib.check(self.lib.dll.lvi_scan_organize(self._h), "lvi_scan_organize")
 

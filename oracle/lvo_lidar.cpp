@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../include/lvi_hotpath.h"
@@ -51,6 +52,10 @@ struct lvi_lidar {
     std::vector<int32_t> col;                        // cloudInfo.point_col_ind
     std::vector<int32_t> startR, endR;
     bool have_org = false;
+    // ---- f-4 (cornerCloudKeyFrames, surfCloudKeyFrames, cloudKeyPoses6D: mapOptimization.cpp:76-81)
+    std::vector<std::vector<lvi_pt>> cornerCloudKeyFrames, surfCloudKeyFrames;
+    std::vector<std::array<float, 6>> keyPoses;
+    size_t kf_points = 0;
     // ---- f-1 (imuDeskewInfo's table, imageProjection.cpp:77-80)
     bool imu_available = false;
     int imuPointerCur = 0;
@@ -754,6 +759,7 @@ void lvi_lidar_params_default(lvi_lidar_params* p)
     p->numberOfCores = 8;
     p->icp_max_iters = 20; p->icp_disable_break = 0;
     p->max_raw_points = 131072; p->max_map_points = 1 << 20; p->voxel_mode = 0;
+    p->max_keyframes = 1024; p->max_keyframe_points = 1 << 22;
 }
 
 int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t /*device*/, lvi_lidar** out)
@@ -878,6 +884,66 @@ int32_t lvi_get_pose_record(lvi_lidar* h, lvi_pose_record* out)
     return LVI_OK;
 }
 
+// ---- f-4 ---------------------------------------------------------------------
+int32_t lvi_keyframe_add(lvi_lidar* h, const lvi_pt* corner, int32_t nc, const lvi_pt* surf, int32_t ns, const float pose[6], int32_t* index_out)
+{
+    if (!h || nc < 0 || ns < 0 || (nc > 0 && !corner) || (ns > 0 && !surf) || !pose) return fail(LVI_ERR_INVALID_ARG, "bad keyframe arguments");
+    if ((int)h->keyPoses.size() >= h->P.max_keyframes || h->kf_points + (size_t)nc + (size_t)ns > (size_t)h->P.max_keyframe_points)
+        return fail(LVI_ERR_CAPACITY, "keyframe store full");
+    h->cornerCloudKeyFrames.emplace_back(corner, corner + nc);               // :1598
+    h->surfCloudKeyFrames.emplace_back(surf, surf + ns);                     // :1599
+    h->keyPoses.push_back({pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]});
+    h->kf_points += (size_t)nc + (size_t)ns;
+    if (index_out) *index_out = (int32_t)h->keyPoses.size() - 1;
+    return LVI_OK;
+}
+int32_t lvi_keyframe_add_current(lvi_lidar* h, const float pose[6], int32_t* index_out)
+{
+    if (!h || !pose) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (!h->have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    return lvi_keyframe_add(h, h->cornerDS.data(), (int32_t)h->cornerDS.size(), h->surfDS.data(), (int32_t)h->surfDS.size(), pose, index_out);
+}
+int32_t lvi_keyframe_set_pose(lvi_lidar* h, int32_t index, const float pose[6])
+{
+    if (!h || !pose || index < 0 || index >= (int32_t)h->keyPoses.size()) return fail(LVI_ERR_INVALID_ARG, "bad keyframe index");
+    for (int k = 0; k < 6; k++) h->keyPoses[index][k] = pose[k];
+    return LVI_OK;
+}
+int32_t lvi_keyframe_count(lvi_lidar* h, int32_t* n_keyframes, int32_t* n_points)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    if (n_keyframes) *n_keyframes = (int32_t)h->keyPoses.size();
+    if (n_points) *n_points = (int32_t)h->kf_points;
+    return LVI_OK;
+}
+int32_t lvi_keyframes_clear(lvi_lidar* h)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    h->cornerCloudKeyFrames.clear(); h->surfCloudKeyFrames.clear(); h->keyPoses.clear(); h->kf_points = 0;
+    return LVI_OK;
+}
+int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys)
+{
+    if (!h || n_keys < 0 || (n_keys > 0 && !key_indices)) return fail(LVI_ERR_INVALID_ARG, "bad key list");
+    size_t tc = 0, ts = 0;
+    for (int i = 0; i < n_keys; i++) {
+        const int k = key_indices[i];
+        if (k < 0 || k >= (int)h->keyPoses.size()) return fail(LVI_ERR_INVALID_ARG, "key index out of range");
+        tc += h->cornerCloudKeyFrames[k].size(); ts += h->surfCloudKeyFrames[k].size();
+    }
+    if (tc > (size_t)h->P.max_map_points || ts > (size_t)h->P.max_map_points) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    std::vector<lvi_pt> c(tc), s(ts);
+    size_t oc = 0, os = 0;
+    for (int i = 0; i < n_keys; i++) {                                      // extractCloud :931-957 (cache or not: same points)
+        const int k = key_indices[i];
+        const lvo::Affine3f t = lvo::trans2Affine3f(h->keyPoses[k].data());    // transformPointCloud :347-354
+        transformPointCloud(h->cornerCloudKeyFrames[k].data(), (int)h->cornerCloudKeyFrames[k].size(), t, c.data() + oc, h->P.numberOfCores);
+        transformPointCloud(h->surfCloudKeyFrames[k].data(), (int)h->surfCloudKeyFrames[k].size(), t, s.data() + os, h->P.numberOfCores);
+        oc += h->cornerCloudKeyFrames[k].size(); os += h->surfCloudKeyFrames[k].size();
+    }
+    return lvi_map_set(h, c.data(), (int32_t)tc, s.data(), (int32_t)ts);
+}
+
 int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
@@ -960,6 +1026,8 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
     const size_t n = h->extracted.size();
     switch (what) {
+        case LVI_DBG_MAP_CORNER_RAW: if (!h->have_map_raw) break; return dbg_copy(h->mapCornerRaw.data(), h->mapCornerRaw.size(), dst, cap, n_bytes);
+        case LVI_DBG_MAP_SURF_RAW:   if (!h->have_map_raw) break; return dbg_copy(h->mapSurfRaw.data(), h->mapSurfRaw.size(), dst, cap, n_bytes);
         case LVI_DBG_CURVATURE:    if (!h->have_feat) break; return dbg_copy(h->cloudCurvature.data(), n, dst, cap, n_bytes);
         case LVI_DBG_PICKED_OCCL:  if (!h->have_feat) break; return dbg_copy(h->pickedOccl.data(), n, dst, cap, n_bytes);
         case LVI_DBG_LABEL:        if (!h->have_feat) break; return dbg_copy(h->cloudLabel.data(), n, dst, cap, n_bytes);

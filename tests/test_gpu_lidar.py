@@ -298,6 +298,49 @@ def test_knn_index_bit_exact_on_identical_map(pkg, oracle, hip):
     o.close(); g.close()
 
 
+# ----------------------------------------------------------------------------- f-4
+def test_map_assemble_matches_oracle(pkg, oracle, hip, scene):
+    """keyframes resident on the device, fused by index list: the raw fused clouds are bit-identical to the oracle's
+    (same host-side libm matrix, same f32 expression), everything downstream as for lvi_map_set"""
+    A = pkg._abi
+    S = pkg.synth
+    o = pkg.LidarHotpath(oracle, **small_params()); g = pkg.LidarHotpath(hip, **small_params())
+    kfs = []
+    for k in range(6):
+        pose = S.loop_pose(0.25 + 0.04 * k, 0.01, -0.01).astype(np.float32)
+        o.scan_upload(S.make_scan(20001, pose, 500 + k)); o.scan_organize(); o.scan_extract(); o.scan_downsample()
+        c, s = o.get_scan_ds()
+        kfs.append((c.copy(), s.copy(), pose))
+    for h in (o, g):
+        for c, s, pose in kfs:
+            h.keyframe_add(c, s, pose)
+        assert h.keyframe_count()[0] == 6
+    order = [5, 2, 0, 3, 1, 4, 2]
+    for h in (o, g):
+        h.map_assemble(order)
+    for what in (A.DBG_MAP_CORNER_RAW, A.DBG_MAP_SURF_RAW):
+        np.testing.assert_array_equal(xyzi(o.debug_get(what, A.PT_DTYPE)).view(np.uint32), xyzi(g.debug_get(what, A.PT_DTYPE)).view(np.uint32))
+    (mco, mso), (mcg, msg) = o.get_map_ds(), g.get_map_ds()
+    assert len(mco) == len(mcg) and len(mso) == len(msg) > 2000
+    np.testing.assert_allclose(xyzi(mso), xyzi(msg), rtol=0, atol=3e-4)
+    # scan matching against the assembled map
+    res = []
+    for h in (o, g):
+        h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+        res.append(h.scan_match(scene["guess"]))
+    assert res[0]["status"] == res[1]["status"] == 0
+    dp = np.abs(res[0]["pose"] - res[1]["pose"])
+    assert dp[:3].max() < 1e-4 and dp[3:].max() < 1e-4
+    # the current scan becomes a keyframe without leaving the device
+    for h, r in zip((o, g), res):
+        assert h.keyframe_add_current(res[0]["pose"]) == 6
+        h.map_assemble([6, 0])
+    ro, rg = xyzi(o.debug_get(A.DBG_MAP_SURF_RAW, A.PT_DTYPE)), xyzi(g.debug_get(A.DBG_MAP_SURF_RAW, A.PT_DTYPE))
+    assert ro.shape == rg.shape
+    np.testing.assert_allclose(ro, rg, rtol=0, atol=3e-4)          # scan DS centroids differ by the documented tolerance
+    o.close(); g.close()
+
+
 # ----------------------------------------------------------------------------- a-7, a-8
 def test_residuals_at_fixed_pose(pkg, pair, scene):
     o, g = pair

@@ -259,6 +259,62 @@ def test_transform_cloud_matches_float64(pkg, L):
     np.testing.assert_array_equal(out[:, 3], pts[:, 3])
 
 
+# ----------------------------------------------------------------------------- f-4 (keyframe store, map assembly)
+def _keyframes(pkg, L, n=5, n_raw=6001):
+    S = pkg.synth
+    kfs = []
+    for k in range(n):
+        pose = S.loop_pose(0.2 + 0.11 * k, 0.01 * k, -0.005 * k)
+        L.scan_upload(S.make_scan(n_raw, pose, 900 + k)); L.scan_organize(); L.scan_extract(); L.scan_downsample()
+        c, s = L.get_scan_ds()
+        kfs.append((c.copy(), s.copy(), pose.astype(np.float32)))
+    return kfs
+
+
+def test_map_assemble_is_transform_and_concatenate(pkg, L):
+    """extractCloud (mapOptimization.cpp:931-957): listed keyframes, in list order, each through transformPointCloud"""
+    A = pkg._abi
+    kfs = _keyframes(pkg, L)
+    for i, (c, s, pose) in enumerate(kfs):
+        assert L.keyframe_add(c, s, pose) == i
+    assert L.keyframe_count() == (len(kfs), sum(len(c) + len(s) for c, s, _ in kfs))
+    order = [3, 0, 4, 0, 1]                                     # any order, duplicates allowed
+    L.map_assemble(order)
+    raw_c, raw_s = L.debug_get(A.DBG_MAP_CORNER_RAW, A.PT_DTYPE), L.debug_get(A.DBG_MAP_SURF_RAW, A.PT_DTYPE)
+    want_c = np.concatenate([xyzi(pkg.synth.transform_points(kfs[k][0], kfs[k][2].astype(np.float64))) for k in order])
+    want_s = np.concatenate([xyzi(pkg.synth.transform_points(kfs[k][1], kfs[k][2].astype(np.float64))) for k in order])
+    assert len(raw_c) == len(want_c) and len(raw_s) == len(want_s) > 1000
+    np.testing.assert_allclose(xyzi(raw_c), want_c, atol=3e-5)          # f32 transform vs the float64 model
+    np.testing.assert_allclose(xyzi(raw_s), want_s, atol=3e-5)
+    # … followed by exactly what lvi_map_set does with those clouds
+    ds_a = [x.copy() for x in L.get_map_ds()]
+    L.map_set(raw_c, raw_s)
+    for a, b in zip(ds_a, L.get_map_ds()):
+        np.testing.assert_array_equal(xyzi(a).view(np.uint32), xyzi(b).view(np.uint32))
+    # a corrected pose (correctPoses :1650-1660) moves that keyframe's points only
+    p2 = kfs[0][2].copy(); p2[3] += 1.0
+    L.keyframe_set_pose(0, p2); L.map_assemble([0, 1])
+    moved = xyzi(L.debug_get(A.DBG_MAP_SURF_RAW, A.PT_DTYPE))
+    n0 = len(kfs[0][1])
+    np.testing.assert_allclose(moved[:n0, 0], want_s[len(kfs[3][1]):len(kfs[3][1]) + n0, 0] + 1.0, atol=3e-5)
+    with pytest.raises(pkg.LviError):
+        L.map_assemble([7])
+    L.keyframes_clear()
+    assert L.keyframe_count() == (0, 0)
+
+
+def test_keyframe_add_current_uses_the_scan_ds_clouds(pkg, L):
+    S = pkg.synth
+    pose = S.loop_pose(0.5)
+    L.scan_upload(S.make_scan(6001, pose, 31)); L.scan_organize(); L.scan_extract(); L.scan_downsample()
+    c, s = L.get_scan_ds()
+    assert L.keyframe_add_current(pose) == 0
+    assert L.keyframe_count() == (1, len(c) + len(s))
+    L.map_assemble([0])
+    A = pkg._abi
+    np.testing.assert_allclose(xyzi(L.debug_get(A.DBG_MAP_SURF_RAW, A.PT_DTYPE)), xyzi(S.transform_points(s, pose)), atol=3e-5)
+
+
 # ----------------------------------------------------------------------------- a-6 … a-10
 def test_knn_debug_is_masked_exact_knn(pkg, L):
     rng = np.random.default_rng(6)
