@@ -546,6 +546,11 @@ struct lvi_tracker {
     // f-2 / f-3
     uint8_t *d_eq = nullptr, *d_lut = nullptr; float *d_un_in = nullptr, *d_un_out = nullptr;
     bool equalize = false; double clahe_clip = 3.0; int clahe_tx = 8, clahe_ty = 8;
+    // pinned staging for incoming frames: the caller's (pageable) image is copied here on the host and goes to the
+    // device from pinned memory — measured: the runtime's own handling of a pageable 0.9 MB source costs up to 1 ms per
+    // frame in a process with many GPU mappings, and the call had to wait for it before returning
+    uint8_t* h_frame[2] = {nullptr, nullptr}; hipEvent_t ev_frame[2] = {nullptr, nullptr}; int frame_slot = 0;
+    float* h_pts[2] = {nullptr, nullptr}; hipEvent_t ev_pts[2] = {nullptr, nullptr}; int pts_slot = 0;      // the same for cur_pts
 };
 
 namespace {
@@ -654,6 +659,14 @@ int32_t lvi_tracker_create(const lvi_tracker_params* p, int32_t device, lvi_trac
         t->arena.init(sz.used + (1 << 16));
         tracker_layout(t->arena, *t);
         LVI_HIP(hipMemsetAsync(t->arena.base, 0, t->arena.size, t->ctx.stream));
+        for (int s = 0; s < 2; s++) {
+            LVI_HIP(hipHostMalloc((void**)&t->h_frame[s], (size_t)t->P.max_width * t->P.max_height, hipHostMallocDefault));
+            LVI_HIP(hipEventCreateWithFlags(&t->ev_frame[s], hipEventDisableTiming));
+            LVI_HIP(hipEventRecord(t->ev_frame[s], t->ctx.stream));
+            LVI_HIP(hipHostMalloc((void**)&t->h_pts[s], sizeof(float) * 2 * (size_t)std::max(t->P.max_features, 64), hipHostMallocDefault));
+            LVI_HIP(hipEventCreateWithFlags(&t->ev_pts[s], hipEventDisableTiming));
+            LVI_HIP(hipEventRecord(t->ev_pts[s], t->ctx.stream));
+        }
         LVI_HIP(hipStreamSynchronize(t->ctx.stream));
         return LVI_OK;
     });
@@ -669,6 +682,12 @@ void lvi_tracker_destroy(lvi_tracker* t)
     if (t->ctx.stream) (void)hipStreamSynchronize(t->ctx.stream);
     t->prof.collect();
     t->arena.release();
+    for (int s = 0; s < 2; s++) {
+        if (t->h_frame[s]) (void)hipHostFree(t->h_frame[s]);
+        if (t->ev_frame[s]) (void)hipEventDestroy(t->ev_frame[s]);
+        if (t->h_pts[s]) (void)hipHostFree(t->h_pts[s]);
+        if (t->ev_pts[s]) (void)hipEventDestroy(t->ev_pts[s]);
+    }
     if (t->ctx.stream) (void)hipStreamDestroy(t->ctx.stream);
     delete t;
 }
@@ -687,19 +706,20 @@ int32_t lvi_tracker_push_image(lvi_tracker* t, const uint8_t* img, int32_t w, in
         if (t->have_forw && (w != t->w || h != t->h)) { t->have_forw = t->have_cur = false; }
         if (t->have_forw) { std::swap(t->cur, t->forw); t->have_cur = true; }     // cur_img = forw_img (:203)
         t->w = w; t->h = h;
-        if (t->equalize) {                                                         // readImage's EQUALIZE branch (:86-90)
-            LVI_HIP(hipMemcpy2DAsync(t->d_stage, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
-            run_clahe(*t, t->d_stage, t->pyr[t->forw].lv[0].px, w, h, t->clahe_clip, t->clahe_tx, t->clahe_ty);
-        } else {
-            LVI_HIP(hipMemcpy2DAsync(t->pyr[t->forw].lv[0].px, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, t->ctx.stream));
-        }
+        const int slot = (t->frame_slot ^= 1);
+        LVI_HIP(hipEventSynchronize(t->ev_frame[slot]));                           // the copy that last used this staging buffer (two frames ago)
+        for (int y = 0; y < h; y++) std::memcpy(t->h_frame[slot] + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+        uint8_t* dst0 = t->equalize ? t->d_stage : t->pyr[t->forw].lv[0].px;
+        LVI_HIP(hipMemcpyAsync(dst0, t->h_frame[slot], (size_t)w * h, hipMemcpyHostToDevice, t->ctx.stream));
+        LVI_HIP(hipEventRecord(t->ev_frame[slot], t->ctx.stream));
+        if (t->equalize) run_clahe(*t, t->d_stage, t->pyr[t->forw].lv[0].px, w, h, t->clahe_clip, t->clahe_tx, t->clahe_ty);   // readImage's EQUALIZE branch (:86-90)
         build_pyramid(*t, t->forw);
         if (!t->have_forw) {                                                       // prev = cur = forw = img (:94-97)
             LVI_HIP(hipMemcpyAsync(t->pyr[t->cur].lv[0].px, t->pyr[t->forw].lv[0].px, (size_t)w * h, hipMemcpyDeviceToDevice, t->ctx.stream));
             build_pyramid(*t, t->cur);
             t->have_cur = true;
         }
-        LVI_HIP(hipStreamSynchronize(t->ctx.stream));                               // caller may reuse its buffer
+        // no stream sync: the caller's buffer was consumed by the host copy above
         t->have_forw = true; t->have_lk = false; t->have_gftt = false;
         return LVI_OK;
     });
@@ -747,8 +767,13 @@ int32_t lvi_tracker_set_points(lvi_tracker* t, const float* cur_xy, int32_t n)
     if (!t || n < 0 || (n > 0 && !cur_xy)) return tfail(LVI_ERR_INVALID_ARG, "bad points");
     if (n > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many points");
     return tguard(t, [&]() -> int32_t {
-        if (n) LVI_HIP(hipMemcpyAsync(t->d_cur_xy, cur_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
-        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        if (n) {
+            const int slot = (t->pts_slot ^= 1);
+            LVI_HIP(hipEventSynchronize(t->ev_pts[slot]));
+            std::memcpy(t->h_pts[slot], cur_xy, sizeof(float) * 2 * (size_t)n);
+            LVI_HIP(hipMemcpyAsync(t->d_cur_xy, t->h_pts[slot], sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
+            LVI_HIP(hipEventRecord(t->ev_pts[slot], t->ctx.stream));
+        }
         t->n_pts = n; t->have_lk = false;
         return LVI_OK;
     });
