@@ -207,6 +207,10 @@ void lvi_lidar_destroy(lvi_lidar* h)
     h->d.arena.release();
     if (h->d.h_icp) (void)hipHostFree(h->d.h_icp);
     if (h->d.h_kfSeg) (void)hipHostFree(h->d.h_kfSeg);
+    for (int s = 0; s < 2; s++) {
+        if (h->d.h_raw[s]) (void)hipHostFree(h->d.h_raw[s]);
+        if (h->d.ev_raw[s]) (void)hipEventDestroy(h->d.ev_raw[s]);
+    }
     if (h->d.graphExec) (void)hipGraphExecDestroy(h->d.graphExec);
     if (h->d.ctx.stream) (void)hipStreamDestroy(h->d.ctx.stream);
     if (h->d.ctx2.stream) (void)hipStreamDestroy(h->d.ctx2.stream);
@@ -229,9 +233,14 @@ int32_t lvi_scan_upload(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw)
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         d.n_raw = n_raw > 0 ? n_raw - 1 : 0;        // moveFromCustomMsg: i < point_num-1 (imageProjection.cpp:249)
-        h2d(d, d.raw, pts, (size_t)d.n_raw);
+        // the caller's (pageable) message is copied to pinned staging on the host and uploaded from there: the call
+        // returns without a stream sync, and the runtime never has to pin / stage the user's memory itself
+        const int slot = (d.raw_slot ^= 1);
+        LVI_HIP(hipEventSynchronize(d.ev_raw[slot]));
+        std::memcpy(d.h_raw[slot], pts, sizeof(lvi_livox_pt) * (size_t)d.n_raw);
+        h2d(d, d.raw, d.h_raw[slot], (size_t)d.n_raw);
+        LVI_HIP(hipEventRecord(d.ev_raw[slot], d.ctx.stream));
         LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
-        sync(d);                                    // the caller's buffer may be reused after return
         d.have_raw = true; d.have_org = d.have_feat = d.have_ds = false;
         return LVI_OK;
     });

@@ -56,6 +56,7 @@ struct LidarDev {
 
     // ---- a-0
     lvi_livox_pt* raw = nullptr; int n_raw = 0;            // after dropping the last point
+    lvi_livox_pt* h_raw[2] = {nullptr, nullptr}; hipEvent_t ev_raw[2] = {nullptr, nullptr}; int raw_slot = 0;   // pinned staging ring of lvi_scan_upload
     // ---- f-4 (keyframe store): clouds in the sensor frame, packed in one pool; tables on the host
     struct KfSeg { int in_off, n, out_off, which; float A[12]; };              // one (keyframe, corner|surf) piece of an assembly
     lvi_pt* kfPool = nullptr; int kf_pool_cap = 0, kf_pool_used = 0;

@@ -667,6 +667,11 @@ void lidar_allocate(LidarDev& d)
     LVI_HIP(hipMemcpyAsync(d.d_fresh, &one, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
     LVI_HIP(hipMemcpyAsync(d.d_dk_first, &int_max, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
     LVI_HIP(hipHostMalloc((void**)&d.h_icp, sizeof(IcpState), hipHostMallocDefault));
+    for (int s = 0; s < 2; s++) {
+        LVI_HIP(hipHostMalloc((void**)&d.h_raw[s], sizeof(lvi_livox_pt) * (size_t)d.raw_cap, hipHostMallocDefault));
+        LVI_HIP(hipEventCreateWithFlags(&d.ev_raw[s], hipEventDisableTiming));
+        LVI_HIP(hipEventRecord(d.ev_raw[s], d.ctx.stream));
+    }
     LVI_HIP(hipHostMalloc((void**)&d.h_kfSeg, sizeof(LidarDev::KfSeg) * (size_t)std::max(d.kf_seg_cap, 1), hipHostMallocDefault));
     // static segment tables of the voxel plans
     std::vector<VoxSegStatic> st(std::max(d.P.N_SCAN, 2));
