@@ -39,6 +39,7 @@ constexpr int VOX_HT = 1024;     // keys per workgroup in the head (segment boun
 constexpr int VB_NB = 4096;      // binned path: bins per segment (LDS histogram of the partition kernels)
 constexpr int VB_CL_LOG = 10;    // binned path: voxels accumulated in LDS per sweep = 1 << VB_CL_LOG
 constexpr int VB_TILE = 4096;    // binned path: points per workgroup in the partition kernels
+constexpr int VB_PAD = 1;        // binned path: stride of the global bin counters / cursors (one per 64-B line, VB_PAD = 16, measured SLOWER: hist 36 vs 29 us, scatter 67 vs 56 us)
 constexpr int VB_CH = 4096;      // binned path: points per accumulate workgroup (chunk of a bin)
 constexpr int VB_ACC_BLOCKS = 1024;
 enum VoxMode { VOX_AUTO = 0, VOX_SORTED = 1, VOX_BINNED = 2 };
@@ -69,6 +70,8 @@ struct VoxelPlan {
     uint2* d_stagingKC = nullptr;     // [nseg][seg_cap]  (voxel idx, point count) beside them
     int* d_chunkStart = nullptr;      // [nseg][VB_NB+1]  exclusive scan of the chunks per bin
     int* d_multiStart = nullptr;      // [nseg][VB_NB+1]  … of the chunks of bins with more than one chunk
+    int* d_chunkBin = nullptr;        // [nseg][max_chunks] bin of every chunk (saves the accumulate kernel a 12-step search through L2)
+    int max_chunks = 0;
     unsigned long long* d_chunkTabV = nullptr;   // [nseg][max_multi][4][1024] chunk tables of multi-chunk bins
     unsigned* d_chunkTabC = nullptr;             // [nseg][max_multi][1024]
     int max_multi = 0;
@@ -90,9 +93,9 @@ struct VoxelPlan {
         d_nout = ar.template alloc<int>(nseg_ + 1);
         nblk_mm = std::max(1, std::min(div_up(seg_cap_, 256 * 16), 1024));
         d_mmPartial = ar.template alloc<float>((size_t)nseg_ * nblk_mm * 12);
-        d_binCount = ar.template alloc<unsigned>((size_t)nseg_ * VB_NB);
+        d_binCount = ar.template alloc<unsigned>((size_t)nseg_ * VB_NB * VB_PAD);
         d_binStart = ar.template alloc<int>((size_t)nseg_ * (VB_NB + 1));
-        d_cursor = ar.template alloc<unsigned>((size_t)nseg_ * VB_NB);
+        d_cursor = ar.template alloc<unsigned>((size_t)nseg_ * VB_NB * VB_PAD);
         d_binVox = ar.template alloc<int>((size_t)nseg_ * VB_NB);
         d_binOut = ar.template alloc<int>((size_t)nseg_ * VB_NB);
         d_bucketed = ar.template alloc<lvi_pt>(tot);
@@ -100,6 +103,8 @@ struct VoxelPlan {
         d_stagingKC = ar.template alloc<uint2>(tot);
         d_chunkStart = ar.template alloc<int>((size_t)nseg_ * (VB_NB + 1));
         d_multiStart = ar.template alloc<int>((size_t)nseg_ * (VB_NB + 1));
+        max_chunks = div_up(seg_cap_, VB_CH) + VB_NB;
+        d_chunkBin = ar.template alloc<int>((size_t)nseg_ * max_chunks);
         max_multi = 2 * div_up(seg_cap_, VB_CH) + 2;         // sum of ceil(cnt/CH) over bins with cnt > CH  <=  2 n / CH
         d_chunkTabV = ar.template alloc<unsigned long long>((size_t)nseg_ * max_multi * (4 << VB_CL_LOG));
         d_chunkTabC = ar.template alloc<unsigned>((size_t)nseg_ * max_multi * (1 << VB_CL_LOG));
