@@ -74,7 +74,7 @@ struct LidarDev {
     int *startR = nullptr, *endR = nullptr, *d_n = nullptr;
     lvi_pt* pts = nullptr; float* range = nullptr; int* col = nullptr;
     // ---- a-1..a-3
-    float* curv = nullptr; uint8_t *picked = nullptr, *picked_occl = nullptr, *surfmask = nullptr; int8_t* label = nullptr;
+    float* curv = nullptr; uint8_t *picked = nullptr, *picked_occl = nullptr, *surfmask = nullptr, *pflags = nullptr; int8_t* label = nullptr;
     int *sector_idx = nullptr, *sector_cnt = nullptr;      // [N_SCAN*6*40], [N_SCAN*6]
     lvi_pt* corner = nullptr; int* corner_idx = nullptr; int* d_ncorner = nullptr;
     lvi_pt* surf = nullptr;                                // concatenated per-ring DS output

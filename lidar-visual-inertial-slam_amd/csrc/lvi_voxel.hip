@@ -530,12 +530,13 @@ __device__ __forceinline__ void vb_zero(VbCells& L, int cells)
 // add bucketed points [q0, q1) whose voxel idx lies in [k0, k0 + cells) to the LDS accumulators
 __device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, const lvi_pt* __restrict__ pts, int q0, int q1, unsigned k0, int cells)
 {
-    for (int i0 = q0 + threadIdx.x; i0 < q1; i0 += 4 * 256) {
-        lvi_pt p[4]; bool ok[4];
+    constexpr int NL = 8;                               // loads in flight per lane
+    for (int i0 = q0 + threadIdx.x; i0 < q1; i0 += NL * 256) {
+        lvi_pt p[NL]; bool ok[NL];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { ok[u] = i0 + u * 256 < q1; if (ok[u]) p[u] = pts[i0 + u * 256]; }
+        for (int u = 0; u < NL; u++) { ok[u] = i0 + u * 256 < q1; if (ok[u]) p[u] = pts[i0 + u * 256]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < NL; u++) {
             if (!ok[u]) continue;
             const unsigned c = vox_key_of_pt(g, p[u]) - k0;
             if (c >= (unsigned)cells) continue;                         // another sub-range of a wide bin
