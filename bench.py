@@ -254,7 +254,9 @@ def main():
     if with_bytes:
         # dominant kernel = largest total time per scan among the kernels of the path
         roofline = roof(with_bytes[0], "HIP events on the launch stream of one of the in-flight scans, profiled pass of the same workload right "
-                                       "after the timed pass; the kernel with the largest total time per scan")
+                                       "after the timed pass; the kernel with the largest total time per scan.  When that kernel is icp_residual: "
+                                       "it is VALU-issue bound on an index that stays in L2 (clock64 phase stamps, DESIGN.md 5), so its HBM "
+                                       "fraction is small by construction; the HBM-bound part of the path is in roofline_streaming_kernel")
         # the path's algorithmic bytes are dominated by the per-scan map re-voxelisation: its widest streaming kernel
         stream = max(with_bytes, key=lambda s: s["bytes_alg"] / s["launches"] if s["avg_us"] > 0 else 0)
         big = [s for s in with_bytes if s["bytes_alg"] / s["launches"] >= 0.5 * stream["bytes_alg"] / stream["launches"]]

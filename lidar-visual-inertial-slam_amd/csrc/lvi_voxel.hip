@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void vb_scatter_kernel(VoxArgs a)
 {
     const int s = blockIdx.y;
     const int n = a.d_n[s];
-    const int base = blockIdx.x * VB_TILE;
+    const int base = blockIdx.x * VB_STILE;
     const VoxGrid& g = a.grid[s];
     if (base >= n || g.nbins == 0) return;
     __shared__ unsigned cnt[VB_NB];
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void vb_scatter_kernel(VoxArgs a)
     const int off = a.dyn[s].in_off;
     const lvi_pt* __restrict__ in = a.st[s].in + off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
-    constexpr int IT = VB_TILE / 256;
+    constexpr int IT = VB_STILE / 256;
     lvi_pt p[IT]; int bin[IT]; unsigned rk[IT];
 #pragma unroll
     for (int u = 0; u < IT; u++) {
@@ -826,7 +826,7 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag,
     LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg), dim3(256), 0, ctx.stream, a));
     LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg), dim3(64), 0, ctx.stream, a));
     if (mode == VOX_BINNED) {
-        const dim3 gt(div_up(p.seg_cap, VB_TILE), p.nseg);
+        const dim3 gt(div_up(p.seg_cap, VB_STILE), p.nseg);
         const dim3 gb(std::min(VB_ACC_BLOCKS, VB_NB), p.nseg);
         const dim3 gh2(std::min(div_up(p.seg_cap, VB_TILE), 512), p.nseg);
         LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, a));
