@@ -331,6 +331,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
 struct GfttArgs {
     const uint8_t* img; const uint8_t* mask; int w, h;
     float* eig; unsigned* maxord; float* thr;
+    unsigned* maxPartial;            // [workgroups of mineig_kernel]
     int* blockCnt; int* total;
     unsigned *keysA, *valsA;
     int *d_n, *d_nbits;
@@ -353,27 +354,36 @@ __device__ __forceinline__ void sobel_at(const uint8_t* img, int w, int h, int x
     Dy = rs2 - rs0;
 }
 
+// Tile of 32 x 8 output pixels: the Sobel products of the 34 x 10 pixels under the 3x3 box are computed ONCE into
+// LDS (the first version recomputed them nine times per pixel), then every thread adds its nine in the reference's
+// order (rows, then columns, in double).  The masked maximum goes to one partial per workgroup; gftt_thr folds them
+// (14 400 wavefronts hitting one atomicMax address cost ~0.16 ms: same-address atomics serialise).
 __global__ __launch_bounds__(256) void mineig_kernel(GfttArgs a)
 {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
-    float val = 0.f; bool in = (x < a.w && y < a.h);
+    constexpr int TW = 34, TH = 10;
+    __shared__ float sxx[TH][TW], sxy[TH][TW], syy[TH][TW];
+    __shared__ unsigned smax[4];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8;
+    const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+    const float k1 = (float)(1.0 * scale), k0 = (float)(2.0 * scale);
+    for (int e = threadIdx.x; e < TW * TH; e += 256) {
+        const int ex = e % TW, ey = e / TW;
+        // the box reads pixel reflect101(x + i), reflect101(y + j); Sobel is evaluated at that in-image pixel
+        const int px = reflect101(x0 - 1 + ex, a.w), py = reflect101(y0 - 1 + ey, a.h);
+        float dx, dy;
+        sobel_at(a.img, a.w, a.h, px, py, k0, k1, dx, dy);
+        sxx[ey][ex] = dx * dx; sxy[ey][ex] = dx * dy; syy[ey][ex] = dy * dy;
+    }
+    __syncthreads();
+    const int x = x0 + tx, y = y0 + ty;
+    float val = 0.f; const bool in = (x < a.w && y < a.h);
     if (in) {
-        const double scale = 1.0 / (4.0 * 3.0 * 255.0);
-        const float k1 = (float)(1.0 * scale), k0 = (float)(2.0 * scale);
         double s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-        for (int j = -1; j <= 1; j++) {
-            const int yy = reflect101(y + j, a.h);
+        for (int j = 0; j < 3; j++)
 #pragma unroll
-            for (int i = -1; i <= 1; i++) {
-                const int xx = reflect101(x + i, a.w);
-                float dx, dy;
-                sobel_at(a.img, a.w, a.h, xx, yy, k0, k1, dx, dy);
-                const float xx2 = dx * dx, xy = dx * dy, yy2 = dy * dy;
-                s0 += xx2; s1 += xy; s2 += yy2;
-            }
-        }
+            for (int i = 0; i < 3; i++) { s0 += sxx[ty + j][tx + i]; s1 += sxy[ty + j][tx + i]; s2 += syy[ty + j][tx + i]; }
         const float A = (float)s0 * 0.5f, B = (float)s1, C = (float)s2 * 0.5f;
         const float t = (A - C) * (A - C), u = B * B;
         val = (A + C) - sqrtf(t + u);
@@ -384,12 +394,23 @@ __global__ __launch_bounds__(256) void mineig_kernel(GfttArgs a)
     unsigned o = counted ? f2ord(val) : 0u;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) { const unsigned t = __shfl_xor(o, s, 64); o = t > o ? t : o; }
-    if (lane_id() == 0 && o) atomicMax(a.maxord, o);
+    if (lane_id() == 0) smax[wave_id()] = o;
+    __syncthreads();
+    if (threadIdx.x == 0) a.maxPartial[blockIdx.y * gridDim.x + blockIdx.x] = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
 }
 
-__global__ void gftt_thr_kernel(GfttArgs a)
+__global__ __launch_bounds__(256) void gftt_thr_kernel(GfttArgs a, int npartial)
 {
-    const unsigned o = *a.maxord;
+    unsigned o = 0u;
+    for (int i = threadIdx.x; i < npartial; i += 256) o = max(o, a.maxPartial[i]);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) { const unsigned t = __shfl_xor(o, s, 64); o = t > o ? t : o; }
+    __shared__ unsigned smax[4];
+    if (lane_id() == 0) smax[wave_id()] = o;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    o = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    *a.maxord = o;
     const double maxVal = o ? (double)ord2f(o) : 0.0;
     *a.thr = (float)(maxVal * a.quality);
     *a.total = 0;
@@ -538,7 +559,7 @@ struct lvi_tracker {
     bool have_forw = false, have_cur = false, have_lk = false, have_gftt = false, have_mask = false;
     uint8_t* d_stage = nullptr;
     float *d_cur_xy = nullptr, *d_forw_xy = nullptr, *d_err = nullptr; uint8_t* d_status = nullptr; int n_pts = 0;
-    uint8_t* d_mask = nullptr; float* d_eig = nullptr; unsigned* d_maxord = nullptr; float* d_thr = nullptr;
+    uint8_t* d_mask = nullptr; float* d_eig = nullptr; unsigned* d_maxord = nullptr; unsigned* d_maxPartial = nullptr; float* d_thr = nullptr;
     int *d_blockCnt = nullptr, *d_total = nullptr, *d_n = nullptr, *d_nbits = nullptr, *d_out_n = nullptr, *d_ncand = nullptr;
     float* d_gftt_xy = nullptr;
     SortPlan sort;
@@ -584,6 +605,7 @@ void tracker_layout(AR& ar, lvi_tracker& t)
     t.d_err = ar.template alloc<float>(F); t.d_status = ar.template alloc<uint8_t>(F);
     t.d_mask = ar.template alloc<uint8_t>((size_t)W * H); t.d_eig = ar.template alloc<float>((size_t)W * H);
     t.d_maxord = ar.template alloc<unsigned>(1); t.d_thr = ar.template alloc<float>(1);
+    t.d_maxPartial = ar.template alloc<unsigned>((size_t)div_up(W, 32) * div_up(H, 8));
     t.d_blockCnt = ar.template alloc<int>(div_up(W * H, CAND_TILE) + 1);
     t.d_total = ar.template alloc<int>(1); t.d_n = ar.template alloc<int>(1); t.d_nbits = ar.template alloc<int>(1);
     t.d_out_n = ar.template alloc<int>(1); t.d_ncand = ar.template alloc<int>(1);
@@ -835,12 +857,12 @@ int32_t lvi_tracker_run_gftt(lvi_tracker* t, int32_t max_corners)
         const int w = t->w, h = t->h, npx = w * h;
         GfttArgs a{};
         a.img = t->pyr[t->forw].lv[0].px; a.mask = t->have_mask ? t->d_mask : nullptr; a.w = w; a.h = h;
-        a.eig = t->d_eig; a.maxord = t->d_maxord; a.thr = t->d_thr; a.blockCnt = t->d_blockCnt; a.total = t->d_total;
+        a.eig = t->d_eig; a.maxord = t->d_maxord; a.maxPartial = t->d_maxPartial; a.thr = t->d_thr; a.blockCnt = t->d_blockCnt; a.total = t->d_total;
         a.keysA = t->sort.keysA; a.valsA = t->sort.valsA; a.d_n = t->d_n; a.d_nbits = t->d_nbits; a.quality = t->P.gftt_quality;
         const int nblk = div_up(npx, CAND_TILE);
         LVI_HIP(hipMemsetAsync(t->d_maxord, 0, sizeof(unsigned), t->ctx.stream));
         LVI_LAUNCH(t->ctx, "gftt_mineig", 2.0 * npx + 4.0 * npx, hipLaunchKernelGGL(mineig_kernel, dim3(div_up(w, 32), div_up(h, 8)), dim3(256), 0, t->ctx.stream, a));
-        LVI_LAUNCH(t->ctx, "gftt_thr", 0, hipLaunchKernelGGL(gftt_thr_kernel, dim3(1), dim3(1), 0, t->ctx.stream, a));
+        LVI_LAUNCH(t->ctx, "gftt_thr", 0, hipLaunchKernelGGL(gftt_thr_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, div_up(w, 32) * div_up(h, 8)));
         LVI_LAUNCH(t->ctx, "gftt_count", 5.0 * npx, hipLaunchKernelGGL(gftt_count_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
         LVI_LAUNCH(t->ctx, "gftt_scan", 0, hipLaunchKernelGGL(gftt_scan_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, nblk));
         LVI_LAUNCH(t->ctx, "gftt_emit", 5.0 * npx, hipLaunchKernelGGL(gftt_emit_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
