@@ -101,10 +101,17 @@ __global__ __launch_bounds__(256) void org_count_kernel(OrgArgs a)
     __syncthreads();
     if (threadIdx.x < a.N_SCAN) a.blockCnt[threadIdx.x * a.nblk + blockIdx.x] = cnt[threadIdx.x];
     if (a.dk_on) {
-        // firstPointFlag (:554): the first point in message order that passes the gates (its column is 0 < Horizon_SCAN)
+        // firstPointFlag (:554): the first point in message order that passes the gates (its column is 0 < Horizon_SCAN);
+        // one atomic per workgroup (same-address atomics serialise)
+        __shared__ int sfirst[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
-        if (lane_id() == 0 && first != 0x7fffffff) atomicMin(a.dk_first, first);
+        if (lane_id() == 0) sfirst[wave_id()] = first;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int f = min(min(sfirst[0], sfirst[1]), min(sfirst[2], sfirst[3]));
+            if (f != 0x7fffffff) atomicMin(a.dk_first, f);
+        }
     }
 }
 
