@@ -184,8 +184,7 @@ __device__ __forceinline__ void knn_insert(KnnKeys& r, unsigned long long key)
 // rows form one flat candidate list read in batches of KNN_KB (adjacent lanes read different rows, the index
 // is L2-resident).  Each lane keeps a private top-5; the G lists are merged by 5 rounds of a group-wide
 // (distance, index) minimum.  All G lanes end with the same result.
-constexpr int KNN_G = 8;
-constexpr int KNN_RPL = 4;                // rows per lane: ceil(25 / KNN_G)
+constexpr int KNN_RPL = (25 + KNN_G - 1) / KNN_G;      // rows per lane
 
 __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
                                                   float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr)

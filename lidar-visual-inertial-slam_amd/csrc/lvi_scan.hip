@@ -688,7 +688,7 @@ void lidar_allocate(LidarDev& d)
     d.kf_pool_cap = d.P.max_keyframes > 0 ? std::max(d.P.max_keyframe_points, 0) : 0;
     d.kf_seg_cap = 2 * std::max(d.P.max_keyframes, 0) + 2048;       // an assembly may list a key more than once
     d.max_cells = 1 << 24;
-    d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / 8);      // 8 lanes per query (KNN_G)
+    d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / KNN_G);
     ArenaSizer sz;
     layout(sz, d);
     d.arena.init(sz.used + (1 << 20));
