@@ -11,7 +11,7 @@ constexpr int ORG_TILE = 1024;          // raw points per workgroup in the organ
 constexpr int FEAT_SEG_CAP = 8192;      // max points of one ring sector held in LDS (+ halo)
 constexpr int MAX_N_SCAN = 32;
 constexpr int CORNERS_PER_SECTOR = 40;  // featureExtraction.cpp:180
-constexpr int KNN_G = 8;                // lanes that share one KNN query (4 lanes: residual 27 us instead of 24, 1 880 instead of 1 960 scans/s)
+constexpr int KNN_G = 8;                // lanes that share one KNN query (measured: 4 lanes 27 us / 1 880 scans/s, 8 lanes 24 us / 1 960, 16 lanes 30 us / 1 725)
 constexpr int ICP_BLOCK = 64 * KNN_G;   // residual workgroup: 64 features x KNN_G lanes
 
 // device status bits (sticky until the next upload)
