@@ -79,6 +79,7 @@ def main():
 
     P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=args.map_points + 65536,
              icp_max_iters=args.icp_iters, icp_disable_break=1,
+             map_on_main_stream=1 if args.inflight >= 4 else 0,       # one stream per hardware queue once >= 4 scans are in flight
              max_keyframes=(args.keyframes + 8) if args.map_source == "assemble" else 0,
              max_keyframe_points=(args.map_points + 200000) if args.map_source == "assemble" else 0)
     B = max(1, args.inflight)

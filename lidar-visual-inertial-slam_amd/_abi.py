@@ -47,7 +47,7 @@ class LidarParams(C.Structure):
                 ("z_tollerance", C.c_float), ("rotation_tollerance", C.c_float), ("imuRPYWeight", C.c_float),
                 ("numberOfCores", C.c_int32), ("icp_max_iters", C.c_int32), ("icp_disable_break", C.c_int32),
                 ("max_raw_points", C.c_int32), ("max_map_points", C.c_int32), ("voxel_mode", C.c_int32),
-                ("max_keyframes", C.c_int32), ("max_keyframe_points", C.c_int32)]
+                ("max_keyframes", C.c_int32), ("max_keyframe_points", C.c_int32), ("map_on_main_stream", C.c_int32)]
 
 
 class ScanInfo(C.Structure):

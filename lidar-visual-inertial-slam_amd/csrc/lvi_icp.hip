@@ -18,6 +18,8 @@
 // (cv::gemm accumulates f32 products in double) to per-workgroup partials, summed in fixed order
 // by a one-wave solve kernel that also does the 6x6 QR solve, the iteration-0 eigen analysis,
 // the pose update and the convergence test, and prepares the next iteration's transform.
+#include <cstdlib>
+
 #include "lvi_lidar.hpp"
 
 namespace lvi {
@@ -917,11 +919,14 @@ void join_map(LidarDev& d)
 // main stream joins it right before scan matching.
 void stage_map_build(LidarDev& d)
 {
-    const Ctx& cx = d.ctx2;
+    const Ctx& cx = d.P.map_on_main_stream ? d.ctx : d.ctx2;
     // everything already enqueued on the main stream (map upload, the previous scan's GN loop reading the
     // previous index) must finish before the map buffers are rewritten
-    LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));
-    LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
+    const bool forked = cx.stream != d.ctx.stream;
+    if (forked) {
+        LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));
+        LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
+    }
     // raw map counts are host-known here; the voxel plan wants them in device memory
     hipLaunchKernelGGL(set_dyn2_kernel, dim3(1), dim3(1), 0, cx.stream, d.voxMap.d_dyn, d.n_map_corner, d.n_map_surf);
     const double n = (double)d.n_map_corner + (double)d.n_map_surf;
@@ -941,8 +946,10 @@ void stage_map_build(LidarDev& d)
     LVI_LAUNCH(cx, "grid_scan_sum", 0, hipLaunchKernelGGL(grid_scan_sum_kernel, dim3(GRID_SCAN_BLOCKS, 2), dim3(256), 0, cx.stream, g));
     LVI_LAUNCH(cx, "grid_scan_apply", 0, hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GRID_SCAN_BLOCKS, 2), dim3(256), 0, cx.stream, g));
     LVI_LAUNCH(cx, "grid_scatter", 32.0 * nds, hipLaunchKernelGGL(grid_scatter_kernel, dim3(GRID_PT_BLOCKS, 2), dim3(256), 0, cx.stream, g));
-    LVI_HIP(hipEventRecord(d.evMap, cx.stream));
-    d.map_pending = true;
+    if (forked) {
+        LVI_HIP(hipEventRecord(d.evMap, cx.stream));
+        d.map_pending = true;
+    }
 }
 
 // f-4.  extractCloud's fuse loop (mapOptimization.cpp:931-957): every listed keyframe cloud through

@@ -420,6 +420,23 @@ def test_fixed_iteration_mode(pkg, oracle, hip, scene):
     o.close(); g.close()
 
 
+def test_map_on_main_stream_gives_identical_results(pkg, hip, scene):
+    """lvi_lidar_params.map_on_main_stream only moves the map build between streams: same bits out"""
+    res = []
+    for mode in (0, 1):
+        g = pkg.LidarHotpath(hip, map_on_main_stream=mode, **small_params())
+        g.map_upload(scene["map_corner"], scene["map_surf"])
+        for rep in range(2):                               # the second round re-voxelises while the first index is still in use
+            g.map_build()
+            g.scan_upload(scene["scan"]); g.scan_organize(); g.scan_extract(); g.scan_downsample()
+            r = g.scan_match(scene["guess"])
+        res.append((r["pose"].copy(), np.array(r["n_sel"]), xyzi(g.get_map_ds()[1]).copy()))
+        g.close()
+    np.testing.assert_array_equal(bits(res[0][0]), bits(res[1][0]))
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2].view(np.uint32), res[1][2].view(np.uint32))
+
+
 # ----------------------------------------------------------------------------- full size
 def test_full_size_scan_properties(pkg, oracle, hip):
     """BASELINE config sizes: 100k-pt scan; size-independent properties + oracle on the scan stages"""
