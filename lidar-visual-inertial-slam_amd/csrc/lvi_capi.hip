@@ -107,6 +107,7 @@ int32_t check_dev_status(LidarDev& d)
 {
     const int st = read_int(d, d.d_status);
     if (st & DEV_ERR_SECTOR_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "a ring sector exceeds FEAT_SEG_CAP points (Horizon_SCAN too large for the LDS-resident sector kernel)");
+    if (st & DEV_ERR_SECTOR_HANDOVER) return fail(LVI_ERR_HIP, "sector kernel: a workgroup never received its predecessor's hand-over word");
     if (st & DEV_ERR_GRID_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "local map extent too large for the KNN grid");
     return LVI_OK;
 }

@@ -15,7 +15,7 @@ constexpr int KNN_G = 8;                // lanes that share one KNN query (measu
 constexpr int ICP_BLOCK = 64 * KNN_G;   // residual workgroup: 64 features x KNN_G lanes
 
 // device status bits (sticky until the next upload)
-enum { DEV_ERR_SECTOR_TOO_LARGE = 1, DEV_ERR_GRID_TOO_LARGE = 2 };
+enum { DEV_ERR_SECTOR_TOO_LARGE = 1, DEV_ERR_GRID_TOO_LARGE = 2, DEV_ERR_SECTOR_HANDOVER = 4 };
 
 struct IcpPose {                         // written by icp_solve for the next residual pass
     float T[6];                          // transformTobeMapped: roll pitch yaw x y z
@@ -76,6 +76,7 @@ struct LidarDev {
     lvi_pt* pts = nullptr; float* range = nullptr; int* col = nullptr;
     // ---- a-1..a-3
     float* curv = nullptr; uint8_t *picked = nullptr, *picked_occl = nullptr, *surfmask = nullptr, *pflags = nullptr; int8_t* label = nullptr;
+    unsigned* sectorSpill = nullptr;                       // [MAX_N_SCAN * 6][2] hand-over words of the pipelined sector kernel
     int *sector_idx = nullptr, *sector_cnt = nullptr;      // [N_SCAN*6*40], [N_SCAN*6]
     lvi_pt* corner = nullptr; int* corner_idx = nullptr; int* d_ncorner = nullptr;
     lvi_pt* surf = nullptr;                                // concatenated per-ring DS output

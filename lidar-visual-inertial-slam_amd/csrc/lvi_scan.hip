@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void org_scatter_kernel(OrgArgs a)
 struct FeatArgs {
     const int* d_n; const float* range; const int* col;
     float* curv; uint8_t *picked, *picked_occl, *surfmask; int8_t* label;
+    unsigned* spill;            // [N_SCAN*6][2] sector hand-over words (see feat_sector_kernel), zeroed by feat_smooth
     uint8_t* pflags;            // bit 0: occlusion mark (= initial picked), bit 1: column jump between k-1 and k; static input of the sector kernel
     const int *startR, *endR, *ringBase; const lvi_pt* pts;
     int *sector_idx, *sector_cnt;
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(256) void feat_smooth_kernel(FeatArgs a)
 {
     const int n = *a.d_n;
     const int k = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) for (int q = threadIdx.x; q < a.N_SCAN * 12; q += 256) a.spill[q] = 0u;
     if (k >= n) return;
     const float* r = a.range;
     float c = 0.f;
@@ -329,12 +331,19 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
     __shared__ int s_ws[FEAT_THREADS / 64 + 2];
     __shared__ int s_any;
 
-    const int ring = blockIdx.x;
+    // One workgroup per (ring, sector) when every sector of the ring is a regular one; the six workgroups of a ring
+    // form a pipeline: loading, neighbour reach, candidate compaction and ranking of sector s+1 run while sector s is
+    // in its greedy walks; what s+1 needs from s — the marks on its first five points — arrives in ONE device-scope
+    // atomic word (5 flag bits + a ready bit), so no memory fence (= L2 write-back on this multi-XCD part) is involved.
+    // Workgroups are dispatched in blockIdx order, a producer always before its consumer, and a ring needs 6 of the
+    // 256 CUs, so a waiting consumer can never keep its producer from running.  Rings with a degenerate sector
+    // (< 66 points) take the sequential form: the sector-0 workgroup walks all six (carry through LDS, as before).
+    const int ring = blockIdx.x / 6, my_sec = blockIdx.x % 6;
     const int n = *a.d_n;
     const int tid = threadIdx.x;
     const int fresh = *a.d_fresh;
     volatile uint8_t* v_pick = s_pick;
-    const bool stamp = (ring == 0 && tid == 0);
+    const bool stamp = (blockIdx.x == 0 && tid == 0);
     long long t_prev = stamp ? clock64() : 0, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
 
@@ -366,10 +375,14 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             pf_fl[i] = in ? a.pflags[k] : (uint8_t)3;
         }
     };
-    prefetch(0);
+    bool piped = true;
+    for (int q = 0; q < 6; q++) { int sp_, ep_; piped = piped && bounds(q, sp_, ep_); }
+    if (!piped && my_sec != 0) return;
+    const int sec_begin = piped ? my_sec : 0, sec_end = piped ? my_sec + 1 : 6;
+    prefetch(sec_begin);
     int carry_k = -1; uint8_t carry_v = 0;            // threads 0..9: picked flags of global points carry_k .. carry_k + 9 as the last sector left them
 
-    for (int sec = 0; sec < 6; sec++) {
+    for (int sec = sec_begin; sec < sec_end; sec++) {
         int sp, ep;
         const bool runnable = bounds(sec, sp, ep);
         int* out_idx = a.sector_idx + (ring * 6 + sec) * CORNERS_PER_SECTOR;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
                 a.sector_cnt[ring * 6 + sec] = 0;                                   // :168 (sp >= ep)
                 if (sp < ep) atomicOr(a.d_status, DEV_ERR_SECTOR_TOO_LARGE);
             }
-            if (sec < 5) prefetch(sec + 1);
+            if (sec + 1 < sec_end) prefetch(sec + 1);
             continue;
         }
         const int k0 = sp - 5;                       // local index j <-> global k = k0 + j
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         }
         __syncthreads();
         if (carry_k >= 0 && tid < 10) { const int j = carry_k + tid - k0; if (j >= 0 && j < L) s_pick[j] = carry_v; }
-        if (sec < 5) prefetch(sec + 1);              // in flight during everything below
+        if (sec + 1 < sec_end) prefetch(sec + 1);    // in flight during everything below
         __syncthreads();
         // reach of the +-5 neighbour marks of a point (they stop at a column break)
 #pragma unroll 4
@@ -412,6 +425,41 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         // candidate in either walk; k = 4 can only be sp of ring 0, sector 0.
         const int jlo = (sp == 4 && ring == 0 && sec == 0) ? 6 : 5;      // first candidate local index
         const int jhi = 5 + (ep - sp);                                    // local index of ep
+        // ---- static part of the surf walk (needs curvature and reach only, so it runs before the hand-over wait):
+        // thread t owns the 16 CONTIGUOUS points [16t, 16t+16); for each of them the set of reachable neighbours that
+        // come EARLIER in the ascending walk is an 11-bit pattern over j-5..j+5 kept in registers.
+        const int jb = tid * FEAT_EPT;
+        unsigned short pat[FEAT_EPT];
+        unsigned statc = 0;                                              // bit i: point jb+i is in [jlo, jhi] with curvature < surfThreshold
+        {
+            float cw[FEAT_EPT + 10];                                     // curvature of j = jb-5 … jb+20
+#pragma unroll
+            for (int q = 0; q < FEAT_EPT + 10; q++) { const int j = jb - 5 + q; cw[q] = (j >= 0) ? s_curv[j] : 0.f; }
+#pragma unroll
+            for (int i = 0; i < FEAT_EPT; i++) {
+                const int j = jb + i;
+                unsigned p = 0;
+                const bool cand = (j >= jlo && j <= jhi && cw[i + 5] < a.surfThreshold);
+                if (cand) {
+                    const float cj = cw[i + 5];
+                    const int rc = s_reach[j];
+                    const int f = rc & 15, bk = rc >> 4;
+#pragma unroll
+                    for (int q = 1; q <= 5; q++) {
+                        if (q <= f && j + q <= jhi) {
+                            const bool earlier = (j + q == jhi) ? false : (cw[i + 5 + q] < cj);      // ties go to the smaller index (j)
+                            if (earlier) p |= 1u << (5 + q);
+                        }
+                        if (q <= bk && j - q >= jlo) {
+                            const bool earlier = (j == jhi) ? true : (cw[i + 5 - q] <= cj);          // ties go to j-q
+                            if (earlier) p |= 1u << (5 - q);
+                        }
+                    }
+                    statc |= 1u << i;
+                }
+                pat[i] = (unsigned short)p;
+            }
+        }
         // ---- corners.  The reference sorts [sp,ep) by curvature and walks ep, then the sorted range from
         // the top, taking a point if it is still unpicked (max 40) and marking its +-5 neighbours.
         // Here: compact the candidates (unpicked, curvature > edgeThreshold), rank-sort them in LDS, and
@@ -435,6 +483,20 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         }
         __syncthreads();
         LVI_STAMP(2);
+        if (piped && sec > 0) {
+            // hand-over from sector sec-1: marks on this sector's first five points (local 5..9)
+            if (tid == 0) {
+                unsigned v = 0u;
+                long long spins = 0;
+                while (!((v = atomicOr(&a.spill[(ring * 6 + sec - 1) * 2], 0u)) & 0x80000000u)) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1ll << 26)) { atomicOr(a.d_status, DEV_ERR_SECTOR_HANDOVER); break; }     // minutes: a lost producer, not contention
+                }
+#pragma unroll
+                for (int i = 0; i < 5; i++) if ((v >> i) & 1u) s_pick[5 + i] = 1;
+            }
+            __syncthreads();
+        }
         if (tid < 64) {
             const int l = tid;
             int taken = 0;
@@ -482,37 +544,10 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         // kept in registers.  A round reads the three halfwords around the chunk of each bitmap, resolves the
         // chunk with shifts and masks, and stores its own halfwords.  Decisions are monotone, so a neighbour
         // chunk's old or new bits are equally valid.
-        const int jb = tid * FEAT_EPT;
-        unsigned short pat[FEAT_EPT];
         unsigned myU = 0, myL = 0;
         {
-            float cw[FEAT_EPT + 10];                                     // curvature of j = jb-5 … jb+20
 #pragma unroll
-            for (int q = 0; q < FEAT_EPT + 10; q++) { const int j = jb - 5 + q; cw[q] = (j >= 0) ? s_curv[j] : 0.f; }
-#pragma unroll
-            for (int i = 0; i < FEAT_EPT; i++) {
-                const int j = jb + i;
-                unsigned p = 0;
-                const bool cand = (j >= jlo && j <= jhi && s_pick[j] == 0 && cw[i + 5] < a.surfThreshold);
-                if (cand) {
-                    const float cj = cw[i + 5];
-                    const int rc = s_reach[j];
-                    const int f = rc & 15, bk = rc >> 4;
-#pragma unroll
-                    for (int q = 1; q <= 5; q++) {
-                        if (q <= f && j + q <= jhi) {
-                            const bool earlier = (j + q == jhi) ? false : (cw[i + 5 + q] < cj);      // ties go to the smaller index (j)
-                            if (earlier) p |= 1u << (5 + q);
-                        }
-                        if (q <= bk && j - q >= jlo) {
-                            const bool earlier = (j == jhi) ? true : (cw[i + 5 - q] <= cj);          // ties go to j-q
-                            if (earlier) p |= 1u << (5 - q);
-                        }
-                    }
-                    myU |= 1u << i;
-                }
-                pat[i] = (unsigned short)p;
-            }
+            for (int i = 0; i < FEAT_EPT; i++) if (((statc >> i) & 1u) && s_pick[jb + i] == 0) myU |= 1u << i;      // candidates the corner walk left unpicked
             s_U[tid + 1] = (unsigned short)myU; s_L[tid + 1] = 0;
         }
         __syncthreads();
@@ -562,13 +597,24 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             }
         }
         __syncthreads();
-        // ---- write back: picked incl. the 5-point spill into the neighbouring sectors, labels, surf candidates
+        if (piped && tid == 0) {
+            // forward word: marks on the next sector's first five points + ready; backward word: marks this sector made on
+            // the previous sector's last five points (feat_finalize ORs them into picked[])
+            unsigned fw = 0x80000000u, bw = 0u;
+#pragma unroll
+            for (int i = 0; i < 5; i++) { if (s_pick[jhi + 1 + i]) fw |= 1u << i; if (s_pick[i]) bw |= 1u << i; }
+            if (sec > 0) atomicExch(&a.spill[(ring * 6 + sec) * 2 + 1], bw);
+            atomicExch(&a.spill[(ring * 6 + sec) * 2], fw);
+        }
+        // ---- write back: picked (sequential form: incl. the 5-point spill into the neighbouring sectors; pipelined form:
+        // the sector's own points, plus the leading / trailing five of the ring's first / last sector), labels, surf candidates
 #pragma unroll 4
         for (int i = 0; i < FEAT_EPT; i++) {
             const int j = tid + i * FEAT_THREADS;
             if (j >= L) break;
             const int k = k0 + j;
             if (k < 0 || k >= n) continue;
+            if (piped && ((j < 5 && sec > 0) || (j > jhi && sec < 5))) continue;
             a.picked[k] = s_pick[j];
             if (j >= 5 && j <= jhi) {
                 const int8_t lb = s_label[j];
@@ -584,7 +630,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
     }
     if (stamp) for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q];
 #undef LVI_STAMP
-    if (ring == 0 && tid == 0 && n > 16) *a.d_fresh = 0;
+    if (blockIdx.x == 0 && tid == 0 && n > 16) *a.d_fresh = 0;
 }
 
 // corners in output order (ring, sector, pick order) + segment descriptors of the per-ring VoxelGrid
@@ -600,6 +646,17 @@ __global__ void feat_finalize_kernel(FeatArgs a)
         for (int r = 0; r < a.N_SCAN; r++) { a.ringDyn[r].in_off = a.ringBase[r]; a.ringDyn[r].n = a.ringBase[r + 1] - a.ringBase[r]; }
     }
     __syncthreads();
+    // pipelined sector kernel: marks a sector made on the last five points of its predecessor
+    for (int t = threadIdx.x; t < ns * 5; t += blockDim.x) {
+        const int s = t / 5, i = t % 5, ring = s / 6, sec = s % 6;
+        if (sec == 0) continue;
+        const unsigned bw = a.spill[s * 2 + 1];
+        if (!((bw >> i) & 1u)) continue;
+        const int sR = a.startR[ring], eR = a.endR[ring];
+        const int sp = (sR * (6 - sec) + eR * sec) / 6;
+        const int k = sp - 5 + i;
+        if (k >= 0 && k < *a.d_n) a.picked[k] = 1;
+    }
     for (int t = threadIdx.x; t < ns * CORNERS_PER_SECTOR; t += blockDim.x) {
         const int s = t / CORNERS_PER_SECTOR, q = t % CORNERS_PER_SECTOR;
         if (q < a.sector_cnt[s]) {
@@ -627,7 +684,7 @@ void layout(AR& ar, LidarDev& d)
     d.startR = ar.template alloc<int>(NS); d.endR = ar.template alloc<int>(NS); d.d_n = ar.template alloc<int>(1);
     d.pts = ar.template alloc<lvi_pt>(d.ext_cap); d.range = ar.template alloc<float>(d.ext_cap); d.col = ar.template alloc<int>(d.ext_cap);
     d.curv = ar.template alloc<float>(d.ext_cap);
-    d.picked = ar.template alloc<uint8_t>(d.ext_cap); d.picked_occl = ar.template alloc<uint8_t>(d.ext_cap); d.pflags = ar.template alloc<uint8_t>(d.ext_cap);
+    d.picked = ar.template alloc<uint8_t>(d.ext_cap); d.picked_occl = ar.template alloc<uint8_t>(d.ext_cap); d.pflags = ar.template alloc<uint8_t>(d.ext_cap); d.sectorSpill = ar.template alloc<unsigned>((size_t)MAX_N_SCAN * 12);
     d.surfmask = ar.template alloc<uint8_t>(d.ext_cap); d.label = ar.template alloc<int8_t>(d.ext_cap);
     d.sector_idx = ar.template alloc<int>((size_t)NS * 6 * CORNERS_PER_SECTOR); d.sector_cnt = ar.template alloc<int>(NS * 6);
     d.corner = ar.template alloc<lvi_pt>(d.ext_cap); d.corner_idx = ar.template alloc<int>((size_t)NS * 6 * CORNERS_PER_SECTOR);
@@ -665,7 +722,7 @@ FeatArgs feat_args(LidarDev& d)
 {
     FeatArgs a{};
     a.d_n = d.d_n; a.range = d.range; a.col = d.col;
-    a.curv = d.curv; a.picked = d.picked; a.picked_occl = d.picked_occl; a.surfmask = d.surfmask; a.label = d.label; a.pflags = d.pflags;
+    a.curv = d.curv; a.picked = d.picked; a.picked_occl = d.picked_occl; a.surfmask = d.surfmask; a.label = d.label; a.pflags = d.pflags; a.spill = d.sectorSpill;
     a.startR = d.startR; a.endR = d.endR; a.ringBase = d.ringBase; a.pts = d.pts;
     a.sector_idx = d.sector_idx; a.sector_cnt = d.sector_cnt;
     a.corner = d.corner; a.corner_idx = d.corner_idx; a.d_ncorner = d.d_ncorner;
@@ -735,7 +792,7 @@ void stage_extract(LidarDev& d)
     FeatArgs a = feat_args(d);
     const double n = d.n_raw;
     LVI_LAUNCH(d.ctx, "feat_smooth", 8.0 * n + 8.0 * n, hipLaunchKernelGGL(feat_smooth_kernel, dim3(div_up(d.ext_cap, 256)), dim3(256), 0, d.ctx.stream, a));
-    LVI_LAUNCH(d.ctx, "feat_sector", 8.0 * n, hipLaunchKernelGGL(feat_sector_kernel, dim3(d.P.N_SCAN), dim3(FEAT_THREADS), 0, d.ctx.stream, a));
+    LVI_LAUNCH(d.ctx, "feat_sector", 8.0 * n, hipLaunchKernelGGL(feat_sector_kernel, dim3(d.P.N_SCAN * 6), dim3(FEAT_THREADS), 0, d.ctx.stream, a));
     LVI_LAUNCH(d.ctx, "feat_finalize", 0, hipLaunchKernelGGL(feat_finalize_kernel, dim3(1), dim3(256), 0, d.ctx.stream, a));
     voxel_downsample_batch(d.ctx, d.voxRing, "ring", n);
 }
