@@ -827,7 +827,7 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag,
     LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg), dim3(64), 0, ctx.stream, a));
     if (mode == VOX_BINNED) {
         const dim3 gt(div_up(p.seg_cap, VB_STILE), p.nseg);
-        const dim3 gb(std::min(VB_ACC_BLOCKS, VB_NB), p.nseg);
+        const dim3 gb(std::max(64, std::min(div_up(p.seg_cap, 2048), VB_ACC_BLOCKS)), p.nseg);       // grid-stride over the bins
         const dim3 gh2(std::min(div_up(p.seg_cap, VB_TILE), 512), p.nseg);
         LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, a));
         LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg), dim3(256), 0, ctx.stream, a));
