@@ -668,14 +668,24 @@ __device__ bool solve6_qr(float A[6][6], float b[6])
 }
 
 // symmetric 6x6 eigen-decomposition (cv::eigen :1268), cyclic Jacobi f32; W descending, rows of V = eigenvectors
+// (every index is a compile-time constant after unrolling: A and V stay in registers; with runtime indices they
+// lived in scratch memory and iteration 0 of the solve kernel took 80 us)
 __device__ void eig6_sym(float A[6][6], float W[6], float V[6][6])
 {
-    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.f : 0.f;
     for (int sweep = 0; sweep < 30; sweep++) {
         float off = 0.f, dia = 0.f;
-        for (int i = 0; i < 6; i++) { dia += fabsf(A[i][i]); for (int j = i + 1; j < 6; j++) off += fabsf(A[i][j]); }
+#pragma unroll
+        for (int i = 0; i < 6; i++) { dia += fabsf(A[i][i]);
+#pragma unroll
+            for (int j = i + 1; j < 6; j++) off += fabsf(A[i][j]); }
         if (off <= 1e-10f * dia || off == 0.f) break;
+#pragma unroll
         for (int p = 0; p < 5; p++)
+#pragma unroll
             for (int q = p + 1; q < 6; q++) {
                 const float apq = A[p][q];
                 if (apq == 0.f) continue;
@@ -683,24 +693,36 @@ __device__ void eig6_sym(float A[6][6], float W[6], float V[6][6])
                 const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
                 const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
                 A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.f;
+#pragma unroll
                 for (int r = 0; r < 6; r++) {
                     if (r == p || r == q) continue;
                     const float arp = A[r][p], arq = A[r][q];
                     A[r][p] = A[p][r] = c * arp - s * arq;
                     A[r][q] = A[q][r] = s * arp + c * arq;
                 }
+#pragma unroll
                 for (int k = 0; k < 6; k++) { const float vp = V[p][k], vq = V[q][k]; V[p][k] = c * vp - s * vq; V[q][k] = s * vp + c * vq; }
             }
     }
+#pragma unroll
     for (int i = 0; i < 6; i++) W[i] = A[i][i];
+    // descending selection sort with compile-time positions: the swap partner is selected by value, not by index
+#pragma unroll
     for (int k = 0; k < 5; k++) {
-        int m = k;
-        for (int i = k + 1; i < 6; i++) if (W[m] < W[i]) m = i;
-        if (m != k) { const float t = W[m]; W[m] = W[k]; W[k] = t; for (int i = 0; i < 6; i++) { const float u = V[m][i]; V[m][i] = V[k][i]; V[k][i] = u; } }
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            // bubble the maximum of W[k..5] into position k: equivalent to "m = argmax (first on ties), swap(k, m)" up to
+            // the order of the remaining entries, which later rounds fix; rows of V follow their eigenvalue
+            if (W[k] < W[i]) {
+                const float t = W[i]; W[i] = W[k]; W[k] = t;
+#pragma unroll
+                for (int c = 0; c < 6; c++) { const float u = V[i][c]; V[i][c] = V[k][c]; V[k][c] = u; }
+            }
+        }
     }
 }
 
-constexpr int SOLVE_THREADS = 1024;
+constexpr int SOLVE_THREADS = 512;      // 1024 would cap the kernel at 128 VGPRs and spill the 6x6 matrices of the serial part
 __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int iter)
 {
     IcpState& s = *a.st;
