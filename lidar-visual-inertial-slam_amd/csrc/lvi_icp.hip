@@ -737,12 +737,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int
         if (k < 28) {
             double v = 0.0;
             constexpr int GS = SOLVE_THREADS / 32;
-            for (int b0 = g; b0 < nb; b0 += 8 * GS) {                   // 8 loads in flight, summed in the fixed order b0, b0+GS, …
-                double t[8];
+            constexpr int NLD = 24;                                     // loads in flight per lane (347 partials / 16 groups = 22 rows)
+            for (int b0 = g; b0 < nb; b0 += NLD * GS) {                 // summed in the fixed order b0, b0+GS, …
+                double t[NLD];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const int b = b0 + u * GS; t[u] = b < nb ? a.partial[(size_t)b * 28 + k] : 0.0; }
+                for (int u = 0; u < NLD; u++) { const int b = b0 + u * GS; t[u] = b < nb ? a.partial[(size_t)b * 28 + k] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 8; u++) v += t[u];
+                for (int u = 0; u < NLD; u++) v += t[u];
             }
             part[g][k] = v;
         }
