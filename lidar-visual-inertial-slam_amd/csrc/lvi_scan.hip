@@ -535,6 +535,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             bool ok = true;
             for (int k = 1; k <= 5; k++) ok = ok && (abs(a.col[k] - a.col[k - 1]) <= 10);
             if (ok && a.surfThreshold > 0.f) s_pick[6] = 1;             // local index of k = 5
+            if (a.surfThreshold > 0.f && n > 0) { a.label[0] = -1; a.picked[0] = 1; }      // ind 0 itself (outside every sector: no effect on the outputs)
         }
         __syncthreads();
         // ---- surf walk as a fixed point (ascending curvature, position ep last; a point is labelled iff no
