@@ -722,7 +722,7 @@ __device__ void eig6_sym(float A[6][6], float W[6], float V[6][6])
     }
 }
 
-constexpr int SOLVE_THREADS = 512;      // 1024 would cap the kernel at 128 VGPRs and spill the 6x6 matrices of the serial part
+constexpr int SOLVE_THREADS = 256;      // 1024 threads cap the kernel at 128 VGPRs (the 6x6 matrices of the serial part spill); 512 x 256 VGPRs need a completely idle CU (26 us under load); 256: 18 us
 __global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int iter)
 {
     IcpState& s = *a.st;
