@@ -1039,6 +1039,8 @@ void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_reco
     const double Q = 0.25 * d.n_raw;       // nominal query count for byte accounting only
     LVI_LAUNCH(d.ctx, "icp_init", 0, hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a, d.d_pose_init, d.have_map ? 1 : 0));
     for (int it = 0; it < a.max_iters; it++) {
+        // (the grid covers ext_cap features; the ~1 200 workgroups beyond the actual count exit at once — measured: launching
+        // exactly the occupied 360 instead changes nothing)
         LVI_LAUNCH(d.ctx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL(icp_residual_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a));
         LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, d.ctx.stream, a, it));
     }
