@@ -488,7 +488,7 @@ struct PickArgs {
 __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
 {
     constexpr int ACC_MAX = 4096;
-    __shared__ short ax[ACC_MAX], ay[ACC_MAX];
+    __shared__ short ax[ACC_MAX], ay[ACC_MAX], acx[ACC_MAX], acy[ACC_MAX];      // accepted corners and their grid cells (no division in the inner loop)
     const unsigned* vals = rs_result_in_B(a.d_nbits[0]) ? a.valsB : a.valsA;
     const int total = *a.total;
     const int l = threadIdx.x;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
         const int xc = x / cell, yc = y / cell;
         if (alive && filter) {
             for (int k = 0; k < nacc; k++) {
-                const int dxc = ax[k] / cell - xc, dyc = ay[k] / cell - yc;
+                const int dxc = acx[k] - xc, dyc = acy[k] - yc;
                 if (dxc < -1 || dxc > 1 || dyc < -1 || dyc > 1) continue;
                 const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
                 if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
@@ -516,15 +516,15 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
         uint64_t m = __ballot(alive);
         while (m && nacc < limit) {
             const int first = __ffsll((long long)m) - 1;
-            const int fx = __shfl(x, first, 64), fy = __shfl(y, first, 64);
+            const int fx = __shfl(x, first, 64), fy = __shfl(y, first, 64), fxc = __shfl(xc, first, 64), fyc = __shfl(yc, first, 64);
             if (l == first) {
-                if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; }
+                if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; acx[nacc] = (short)xc; acy[nacc] = (short)yc; }
                 a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y;
                 alive = false;
             }
             nacc++;
             if (alive && filter) {
-                const int dxc = fx / cell - xc, dyc = fy / cell - yc;
+                const int dxc = fxc - xc, dyc = fyc - yc;
                 if (dxc >= -1 && dxc <= 1 && dyc >= -1 && dyc <= 1) {
                     const float dx = (float)(x - fx), dy = (float)(y - fy);
                     if ((double)(dx * dx + dy * dy) < md2) alive = false;
