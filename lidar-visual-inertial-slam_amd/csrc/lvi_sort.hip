@@ -20,8 +20,10 @@ struct SortArgs {
     int seg_cap, nblk;
 };
 
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(SortArgs a, const int* __restrict__ d_n, const int* __restrict__ d_nbits, int pass)
 {
+    constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     const int s = blockIdx.y;
     const int shift = pass * 8;
     if (shift >= d_nbits[s]) return;
@@ -42,8 +44,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(SortArgs a, const i
 }
 
 // grid (256 digits, nseg): exclusive scan of hist[s][d][0..tiles) in place, total to digitTotal
+template <int RS_ITEMS>
 __global__ __launch_bounds__(256) void rs_scan_kernel(SortArgs a, const int* __restrict__ d_n, const int* __restrict__ d_nbits, int pass)
 {
+    constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     const int s = blockIdx.y, d = blockIdx.x;
     if (pass * 8 >= d_nbits[s]) return;
     const int n = d_n[s];
@@ -62,8 +66,10 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(SortArgs a, const int* __r
     if (threadIdx.x == 0) a.digitTotal[s * 256 + d] = (unsigned)carry;
 }
 
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(SortArgs a, const int* __restrict__ d_n, const int* __restrict__ d_nbits, int pass)
 {
+    constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
     const int s = blockIdx.y;
     const int shift = pass * 8;
     if (shift >= d_nbits[s]) return;
@@ -158,9 +164,15 @@ void radix_sort_pairs(const Ctx& ctx, const SortPlan& p, const int* d_n, const i
     snprintf(nm[1], sizeof(nm[1]), "rs_scan/%s", tag);
     snprintf(nm[2], sizeof(nm[2]), "rs_scatter/%s", tag);
     for (int pass = 0; pass < max_passes; pass++) {
-        LVI_LAUNCH(ctx, nm[0], 4.0 * n_hint, hipLaunchKernelGGL(rs_hist_kernel, gt, dim3(RS_THREADS), 0, ctx.stream, a, d_n, d_nbits, pass));
-        LVI_LAUNCH(ctx, nm[1], 0.0, hipLaunchKernelGGL(rs_scan_kernel, gs, dim3(256), 0, ctx.stream, a, d_n, d_nbits, pass));
-        LVI_LAUNCH(ctx, nm[2], 16.0 * n_hint, hipLaunchKernelGGL(rs_scatter_kernel, gt, dim3(RS_THREADS), 0, ctx.stream, a, d_n, d_nbits, pass));
+        if (p.items == RS_ITEMS_SMALL) {
+            LVI_LAUNCH(ctx, nm[0], 4.0 * n_hint, hipLaunchKernelGGL(rs_hist_kernel<RS_ITEMS_SMALL>, gt, dim3(RS_THREADS), 0, ctx.stream, a, d_n, d_nbits, pass));
+            LVI_LAUNCH(ctx, nm[1], 0.0, hipLaunchKernelGGL(rs_scan_kernel<RS_ITEMS_SMALL>, gs, dim3(256), 0, ctx.stream, a, d_n, d_nbits, pass));
+            LVI_LAUNCH(ctx, nm[2], 16.0 * n_hint, hipLaunchKernelGGL(rs_scatter_kernel<RS_ITEMS_SMALL>, gt, dim3(RS_THREADS), 0, ctx.stream, a, d_n, d_nbits, pass));
+        } else {
+            LVI_LAUNCH(ctx, nm[0], 4.0 * n_hint, hipLaunchKernelGGL(rs_hist_kernel<RS_ITEMS>, gt, dim3(RS_THREADS), 0, ctx.stream, a, d_n, d_nbits, pass));
+            LVI_LAUNCH(ctx, nm[1], 0.0, hipLaunchKernelGGL(rs_scan_kernel<RS_ITEMS>, gs, dim3(256), 0, ctx.stream, a, d_n, d_nbits, pass));
+            LVI_LAUNCH(ctx, nm[2], 16.0 * n_hint, hipLaunchKernelGGL(rs_scatter_kernel<RS_ITEMS>, gt, dim3(RS_THREADS), 0, ctx.stream, a, d_n, d_nbits, pass));
+        }
     }
 }
 

@@ -8,18 +8,20 @@ namespace lvi {
 constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;      // 4096 pairs per workgroup
+constexpr int RS_ITEMS_SMALL = 4;                   // 1024-pair tiles: plans whose live size is a few 10^4 pairs whatever the capacity (GFTT candidates)
 
 struct SortPlan {
     int nseg = 0;
     int seg_cap = 0;                 // every segment owns [s*seg_cap, (s+1)*seg_cap) of the four arrays
-    int nblk = 0;                    // tiles per segment = ceil(seg_cap / RS_TILE)
+    int nblk = 0;                    // tiles per segment = ceil(seg_cap / (RS_THREADS * items))
+    int items = RS_ITEMS;            // pairs per thread and tile: RS_ITEMS or RS_ITEMS_SMALL
     unsigned *keysA = nullptr, *valsA = nullptr, *keysB = nullptr, *valsB = nullptr;
     unsigned* hist = nullptr;        // [nseg][256][nblk]  per-tile digit counts, scanned in place
     unsigned* digitTotal = nullptr;  // [nseg][256]
 
-    template <class AR> void allocate(AR& ar, int nseg_, int seg_cap_)
+    template <class AR> void allocate(AR& ar, int nseg_, int seg_cap_, int items_ = RS_ITEMS)
     {
-        nseg = nseg_; seg_cap = seg_cap_; nblk = div_up(seg_cap_, RS_TILE);
+        nseg = nseg_; seg_cap = seg_cap_; items = items_; nblk = div_up(seg_cap_, RS_THREADS * items_);
         size_t tot = (size_t)nseg * seg_cap;
         keysA = ar.template alloc<unsigned>(tot); valsA = ar.template alloc<unsigned>(tot);
         keysB = ar.template alloc<unsigned>(tot); valsB = ar.template alloc<unsigned>(tot);

@@ -610,7 +610,7 @@ void tracker_layout(AR& ar, lvi_tracker& t)
     t.d_total = ar.template alloc<int>(1); t.d_n = ar.template alloc<int>(1); t.d_nbits = ar.template alloc<int>(1);
     t.d_out_n = ar.template alloc<int>(1); t.d_ncand = ar.template alloc<int>(1);
     t.d_gftt_xy = ar.template alloc<float>(2 * (size_t)F);
-    t.sort.allocate(ar, 1, W * H);
+    t.sort.allocate(ar, 1, W * H, RS_ITEMS_SMALL);
     t.d_stage = ar.template alloc<uint8_t>((size_t)W * H); t.d_eq = ar.template alloc<uint8_t>((size_t)W * H);
     t.d_lut = ar.template alloc<uint8_t>((size_t)CLAHE_MAX_TILES * CLAHE_MAX_TILES * 256);
     t.d_un_in = ar.template alloc<float>(2 * (size_t)F); t.d_un_out = ar.template alloc<float>(2 * (size_t)F);
