@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--enqueue", choices=["graph", "eager", "threads"], default="eager",
                     help="how the per-scan launch sequence is issued: one hipGraph launch per scan, eager launches from one host "
                          "thread, or eager launches from one host thread per in-flight scan (ctypes releases the GIL)")
+    ap.add_argument("--map-stream", type=int, default=-1, help="lvi_lidar_params.map_on_main_stream: -1 auto (1 when >= 4 scans in flight), 0, 1")
+    ap.add_argument("--step-sync", action="store_true",
+                    help="synchronise every handle at the end of each step instead of only before a handle is reused")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-tracker", action="store_true")
@@ -79,7 +82,7 @@ def main():
 
     P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=args.map_points + 65536,
              icp_max_iters=args.icp_iters, icp_disable_break=1,
-             map_on_main_stream=1 if args.inflight >= 4 else 0,       # one stream per hardware queue once >= 4 scans are in flight
+             map_on_main_stream=(1 if args.inflight >= 4 else 0) if args.map_stream < 0 else args.map_stream,   # one stream per hardware queue once >= 4 scans are in flight
              max_keyframes=(args.keyframes + 8) if args.map_source == "assemble" else 0,
              max_keyframe_points=(args.map_points + 200000) if args.map_source == "assemble" else 0)
     B = max(1, args.inflight)
@@ -144,13 +147,19 @@ def main():
 
     enq = [0.0]
 
+    rolling = args.enqueue in ("eager", "threads") and not args.step_sync
+    pending = [None]          # rolling mode: index of the step whose records have not been gathered yet
+
     def step(i):
         t_e = time.perf_counter()
-        # B independent scans: everything is enqueued for all of them before the first sync, so the GPU
-        # interleaves their (mostly latency-bound) kernels; each handle has two streams of its own
+        # B independent scans in flight.  Rolling form (default): a handle is synchronised only right before it gets its
+        # next scan, so while the host enqueues handle 0's scan of step i+1 the other handles are still busy with step i —
+        # no queue ever waits for the host to finish enqueueing its neighbours.  (--step-sync: enqueue all, then sync all.)
         def one(b):
             h = hs[b]
             k = (i * B + b) % args.pool
+            if rolling:
+                h.sync()                                                  # its scan of step i-1 is complete
             if args.enqueue == "graph":
                 # one C-ABI call per scan: D2D of the 2 MB scan + one hipGraph launch of the whole path
                 h.scan_replay_enqueue(d_scans[k].data_ptr(), args.n_raw, guesses[k], d_rec[i * B + b].data_ptr(), rebuild_map=not args.frozen_map)
@@ -163,7 +172,7 @@ def main():
                 h.scan_upload_device(d_scans[k].data_ptr(), args.n_raw)   # D2D, 2 MB
                 h.scan_organize(); h.scan_extract(); h.scan_downsample()
                 h.scan_match_async(guesses[k], d_rec[i * B + b].data_ptr())
-            if args.enqueue == "threads":
+            if args.enqueue == "threads" and not rolling:
                 h.sync()
         if args.enqueue == "threads" and B > 1:
             list(pool.map(one, range(B)))
@@ -171,10 +180,24 @@ def main():
             for b in range(B):
                 one(b)
         enq[0] += time.perf_counter() - t_e
+        if rolling:
+            # every handle was synchronised above before its new scan went in: the records of step i-1 are final
+            j, pending[0] = pending[0], i
+            if world > 1 and j is not None:
+                pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
+            return
         for h in hs:
             h.sync()
         if world > 1:
             pkg.replay.gather_records(d_rec[i * B:(i + 1) * B], world, dist)   # RCCL all_gather: 32 B pose record per scan
+
+    def flush():
+        """rolling mode: finish the step still in flight and gather its records (inside the timed region)"""
+        for h in hs:
+            h.sync()
+        j, pending[0] = pending[0], None
+        if rolling and world > 1 and j is not None:
+            pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
 
     def fence():
         torch.cuda.synchronize()
@@ -184,11 +207,13 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    flush()
     fence()
     enq[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    flush()
     fence()
     elapsed = time.perf_counter() - t0
     enqueue_ms_per_scan = 1e3 * enq[0] / (args.steps * B)
@@ -221,7 +246,7 @@ def main():
     g.prof_reset(); g.prof_enable(True)
     for i in range(args.warmup + args.steps, total):
         step(i)
-    g.sync()
+    flush()
     stats = g.prof_read()
     g.prof_enable(False)
     for s in stats:
@@ -274,6 +299,7 @@ def main():
                     n_raw=args.n_raw, map_raw_points=nc + ns, map_ds_points=cnt_map["map_corner_ds"] + cnt_map["map_surf_ds"],
                     scan_features=dict(corner=cnt["corner"], surf=cnt["surf"], corner_ds=cnt["corner_ds"], surf_ds=cnt["surf_ds"]),
                     icp_iters=args.icp_iters, map_source=args.map_source, scans_in_flight_per_gpu=B, scans_per_step=world * B, enqueue=args.enqueue,
+                    handle_sync="per step" if not rolling else "per handle, before it is reused",
                     sharding="independent scans sharded across ranks (B in flight per rank), RCCL all_gather of pose records per step"),
         roofline=roofline, roofline_streaming_kernel=roofline_bw,
         results_ok=ok, pose_err_vs_truth=dict(trans_m=err_t, rot_rad=err_r),
