@@ -832,7 +832,7 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag,
         LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, a));
         LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg), dim3(256), 0, ctx.stream, a));
         LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, a));
-        const dim3 ga(std::max(128, std::min(2 * div_up(p.seg_cap, VB_CH), 2048)), p.nseg);      // grid-stride over the chunks
+        const dim3 ga(std::max(256, std::min(2 * div_up(p.seg_cap, VB_CH), 2048)), p.nseg);      // grid-stride over the chunks
         LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel, ga, dim3(256), 0, ctx.stream, a));
         LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, gb, dim3(256), 0, ctx.stream, a));
         LVI_LAUNCH(ctx, nm[11], 0, hipLaunchKernelGGL(vb_outscan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
