@@ -149,6 +149,39 @@ def test_extract_features_one_call_seam(pair, scene):
     np.testing.assert_allclose(xyzi(s_o), xyzi(s_g), rtol=0, atol=2e-5)
 
 
+def test_sector_kernel_geometries(pkg, oracle, hip):
+    """the pipelined (ring, sector) form, the sequential fallback for rings with a degenerate sector (fewer than 66
+    points), empty rings, more rings than the default and the yaml's Horizon_SCAN: indices and labels exact"""
+    S = pkg.synth
+    A = pkg._abi
+    base = S.make_scan(24001, S.loop_pose(0.9, 0.01, 0.02), 404)
+    cases = []
+    thin = base.copy()                                  # ring 3 keeps 40 points, ring 2 none
+    idx3 = np.flatnonzero(thin["line"] == 3)
+    thin["line"][idx3[40:]] = 9                         # an invalid line is dropped (imageProjection.cpp:586-588)
+    thin["line"][thin["line"] == 2] = 9
+    cases.append((dict(N_SCAN=4, Horizon_SCAN=8192), thin))
+    six = base.copy(); six["line"] = (np.arange(len(six)) % 6).astype(np.uint8)
+    cases.append((dict(N_SCAN=6, Horizon_SCAN=6000), six))          # yaml Horizon_SCAN, six rings
+    tiny = base[:300].copy()                            # every ring degenerate
+    cases.append((dict(N_SCAN=4, Horizon_SCAN=8192), tiny))
+    for kw, scan in cases:
+        P = dict(max_raw_points=40000, max_map_points=400000); P.update(kw)
+        o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P)
+        for rep in range(2):                            # second scan on the same handles: not the "fresh node" case
+            for h in (o, g):
+                h.scan_upload(scan); h.scan_organize(); h.scan_extract()
+            n = o.get_scan_info()["n"]
+            np.testing.assert_array_equal(o.debug_get(A.DBG_CORNER_INDEX, np.int32), g.debug_get(A.DBG_CORNER_INDEX, np.int32))
+            if n > 10:                                  # entries outside [5, n-5) are never reset by the reference (stale across scans) and never read
+                np.testing.assert_array_equal(o.debug_get(A.DBG_LABEL, np.int32)[5:n - 5], g.debug_get(A.DBG_LABEL, np.int32)[5:n - 5])
+                np.testing.assert_array_equal(o.debug_get(A.DBG_PICKED_FINAL, np.int32)[5:n - 5], g.debug_get(A.DBG_PICKED_FINAL, np.int32)[5:n - 5])
+            (co, so), (cg, sg) = o.get_features(), g.get_features()
+            np.testing.assert_array_equal(xyzi(co).view(np.uint32), xyzi(cg).view(np.uint32))
+            assert len(so) == len(sg)
+        o.close(); g.close()
+
+
 # ----------------------------------------------------------------------------- a-4
 def _voxel_case(pkg, o, g, pts, leaf):
     A = pkg._abi
