@@ -723,7 +723,9 @@ __device__ void eig6_sym(float A[6][6], float W[6], float V[6][6])
 }
 
 constexpr int SOLVE_THREADS = 256;      // 1024 threads cap the kernel at 128 VGPRs (the 6x6 matrices of the serial part spill); 512 x 256 VGPRs need a completely idle CU (26 us under load); 256: 18 us
-__global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int iter)
+__device__ void icp_finish_body(const IcpArgs& a);      // transformUpdate + the pose record, defined below
+
+__device__ __forceinline__ void icp_solve_body(const IcpArgs& a, int iter)
 {
     IcpState& s = *a.st;
     if (s.done) return;
@@ -844,7 +846,16 @@ __device__ void q_to_rpy(const Quatd& q, double& roll, double& pitch, double& ya
     else { pitch = -asin(m20); roll = atan2(m21 / cos(pitch), m22 / cos(pitch)); yaw = atan2(m10 / cos(pitch), m00 / cos(pitch)); }
 }
 
-__global__ void icp_finish_kernel(IcpArgs a)
+// the last iteration's solve launch also finishes the scan (one launch less on the critical path)
+__global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int iter, int last)
+{
+    icp_solve_body(a, iter);                    // threads other than 0 come back early
+    if (last && threadIdx.x == 0) icp_finish_body(a);
+}
+
+__global__ void icp_finish_kernel(IcpArgs a) { icp_finish_body(a); }       // only launched when icp_max_iters == 0
+
+__device__ void icp_finish_body(const IcpArgs& a)
 {
     IcpState& s = *a.st;
     float* T = s.pose.T;
@@ -951,7 +962,7 @@ void stage_map_build(LidarDev& d)
         LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
     }
     // raw map counts are host-known here; the voxel plan wants them in device memory
-    hipLaunchKernelGGL(set_dyn2_kernel, dim3(1), dim3(1), 0, cx.stream, d.voxMap.d_dyn, d.n_map_corner, d.n_map_surf);
+    d.voxMap.n_host[0] = d.n_map_corner; d.voxMap.n_host[1] = d.n_map_surf; d.voxMap.use_n_host = true;       // instead of a 1-thread launch writing d_dyn
     const double n = (double)d.n_map_corner + (double)d.n_map_surf;
     voxel_downsample_batch(cx, d.voxMap, "map", n);
 
@@ -1042,9 +1053,9 @@ void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_reco
         // (the grid covers ext_cap features; the ~1 200 workgroups beyond the actual count exit at once — measured: launching
         // exactly the occupied 360 instead changes nothing)
         LVI_LAUNCH(d.ctx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL(icp_residual_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a));
-        LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, d.ctx.stream, a, it));
+        LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, d.ctx.stream, a, it, it == a.max_iters - 1 ? 1 : 0));
     }
-    LVI_LAUNCH(d.ctx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a));
+    if (a.max_iters <= 0) LVI_LAUNCH(d.ctx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a));
 }
 
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd)

@@ -60,6 +60,8 @@ struct VoxelPlan {
     float* d_mmPartial = nullptr;  // [nseg][nblk_mm][12] per-workgroup bbox partials
     int nblk_mm = 0;
     // binned path
+    int n_host[4] = {0, 0, 0, 0};     // plans whose segment lengths the host knows (the raw map): passed as kernel arguments
+    bool use_n_host = false;          // instead of d_dyn[].n (in_off stays 0)
     int mode = VOX_AUTO;
     unsigned* d_binCount = nullptr;   // [nseg][VB_NB]    points per bin (zero between runs)
     int* d_binStart = nullptr;        // [nseg][VB_NB+1]  first bucketed position of every bin
