@@ -668,12 +668,6 @@ __global__ void feat_finalize_kernel(FeatArgs a)
     }
 }
 
-__global__ void scan_ds_prep_kernel(VoxSegDyn* dyn, const int* d_ncorner, const int* d_nsurf)
-{
-    dyn[0].in_off = 0; dyn[0].n = *d_ncorner;
-    dyn[1].in_off = 0; dyn[1].n = *d_nsurf;
-}
-
 template <class AR>
 void layout(AR& ar, LidarDev& d)
 {
@@ -773,6 +767,8 @@ void lidar_allocate(LidarDev& d)
     st[1] = VoxSegStatic{d.mapSurfRaw, nullptr, d.mapSurfDS, d.P.mappingSurfLeafSize};
     d.voxMap.set_static(d.ctx, st.data());
     d.voxRing.mode = d.voxScan.mode = d.voxMap.mode = d.voxGen.mode = d.P.voxel_mode;
+    // the scan grids take their input counts straight from the producers' device counters (no 1-thread launch in between)
+    d.voxScan.n_dev[0] = d.d_ncorner; d.voxScan.n_dev[1] = d.voxRing.d_nout + d.P.N_SCAN;
     LVI_HIP(hipStreamSynchronize(d.ctx.stream));
 }
 
@@ -800,8 +796,6 @@ void stage_extract(LidarDev& d)
 
 void stage_downsample(LidarDev& d)
 {
-    LVI_LAUNCH(d.ctx, "scan_ds_prep", 0, hipLaunchKernelGGL(scan_ds_prep_kernel, dim3(1), dim3(1), 0, d.ctx.stream,
-                                                           d.voxScan.d_dyn, d.d_ncorner, d.voxRing.d_nout + d.P.N_SCAN));
     voxel_downsample_batch(d.ctx, d.voxScan, "scan", 0.4 * d.n_raw);
 }
 

@@ -35,11 +35,12 @@ struct VoxArgs {
     int* chunkBin; int max_chunks;                     // [nseg][max_chunks]
     unsigned long long* chunkTabV; unsigned* chunkTabC; int max_multi;   // [nseg][max_multi] LDS tables of the chunks of multi-chunk bins
     int n_host[4]; int use_n_host;                     // host-known segment lengths (raw map), else dyn[].n
+    const int* n_dev[4];                               // producer's device counters (scan grids), else dyn[].n
 };
 
 __device__ __forceinline__ int seg_len(const VoxArgs& a, int s)
 {
-    const int n = a.use_n_host ? a.n_host[s] : a.dyn[s].n;
+    const int n = a.use_n_host ? a.n_host[s] : ((s < 4 && a.n_dev[s]) ? *a.n_dev[s] : a.dyn[s].n);
     return n < 0 ? 0 : (n > a.seg_cap ? a.seg_cap : n);
 }
 
@@ -752,7 +753,8 @@ static VoxArgs make_args(const VoxelPlan& p)
                    p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm,
                    p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
                    p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
-                   {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0};
+                   {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0,
+                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}};
 }
 
 void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs)

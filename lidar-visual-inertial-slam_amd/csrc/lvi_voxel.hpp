@@ -62,6 +62,7 @@ struct VoxelPlan {
     // binned path
     int n_host[4] = {0, 0, 0, 0};     // plans whose segment lengths the host knows (the raw map): passed as kernel arguments
     bool use_n_host = false;          // instead of d_dyn[].n (in_off stays 0)
+    const int* n_dev[4] = {nullptr, nullptr, nullptr, nullptr};   // or: device counters of the producer (scan grids), in_off 0
     int mode = VOX_AUTO;
     unsigned* d_binCount = nullptr;   // [nseg][VB_NB]    points per bin (zero between runs)
     int* d_binStart = nullptr;        // [nseg][VB_NB+1]  first bucketed position of every bin
