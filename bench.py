@@ -71,11 +71,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda unavailable)")
+    # rehearsal switches for a ONE-GPU box (the N > 1 code path with gloo, every rank on cuda:0); never set by the driver
+    rehearse = os.environ.get("LVI_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     pkg = graft.import_package()
     A, S = pkg._abi, pkg.synth
     hip = pkg.load_hip()                      # raises when the HIP library is missing: no fallback
