@@ -45,17 +45,18 @@ def kernel(d, out):
 
 
 def steady(d, out, nsteps):
-    """per-kernel table over the LAST nsteps bench steps only (a step ends with icp_finish_kernel), so that
+    """per-kernel table over the LAST nsteps bench steps only (a period starts with org_count_kernel), so that
     set-up work (map generation, torch kernels) does not dilute the averages.  Kernels of the same name but
     different launch geometry (ring / scan / map voxel batches) are kept apart by their grid size."""
     rows = []
     for f in find(d, "*kernel_trace.csv"):
         rows += list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "icp_finish_kernel" in r["Kernel_Name"]]
+    # a scan's scan-side chain starts with org_count_kernel: N + 1 of them delimit N whole periods of the steady state
+    ends = [i for i, r in enumerate(rows) if "org_count_kernel" in r["Kernel_Name"]]
     if len(ends) < nsteps + 1:
         raise SystemExit("not enough steps in the trace")
-    seg = rows[ends[-nsteps - 1] + 1: ends[-1] + 1]
+    seg = rows[ends[-nsteps - 1]: ends[-1]]
     t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     for r in seg:
@@ -82,15 +83,14 @@ def steady(d, out, nsteps):
 
 
 def pmc(fd, wd, out, nsteps=3):
-    """HBM bytes per launch per kernel AND launch geometry, over the last nsteps bench steps (a step ends with
-    icp_finish_kernel).  rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE are separate passes (TCC slots)."""
+    """HBM bytes per launch per kernel AND launch geometry, over the last nsteps bench steps (a period starts with org_count_kernel).  rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE are separate passes (TCC slots)."""
     def per_kernel(d, counter):
         rows = []
         for f in find(d, "*counter_collection.csv"):
             rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        ends = [i for i, r in enumerate(rows) if "icp_finish_kernel" in r["Kernel_Name"]]
-        seg = rows[ends[-nsteps - 1] + 1: ends[-1] + 1] if len(ends) > nsteps else rows
+        ends = [i for i, r in enumerate(rows) if "org_count_kernel" in r["Kernel_Name"]]
+        seg = rows[ends[-nsteps - 1]: ends[-1]] if len(ends) > nsteps else rows
         agg = defaultdict(lambda: [0, 0.0])
         for r in seg:
             a = agg[f'{short(r["Kernel_Name"])} [grid {r["Grid_Size"]}, wg {r["Workgroup_Size"]}]']
