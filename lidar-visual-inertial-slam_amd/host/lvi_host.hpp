@@ -142,6 +142,25 @@ public:
                           laserCloudSurfFromMap.data(), (int32_t)laserCloudSurfFromMap.size()), "lvi_map_set");
         haveMap_ = true;
     }
+    // f-4: saveKeyFramesAndFactor's two push_backs (:1594-1599) with the clouds staying on the device …
+    int saveKeyFrame()
+    {
+        int32_t idx = -1;
+        check(lvi_keyframe_add_current(h_.get(), transformTobeMapped, &idx), "lvi_keyframe_add_current");
+        return idx;
+    }
+    int saveKeyFrame(const std::vector<lvi_pt>& cornerDS, const std::vector<lvi_pt>& surfDS, const float pose[6])
+    {
+        int32_t idx = -1;
+        check(lvi_keyframe_add(h_.get(), cornerDS.data(), (int32_t)cornerDS.size(), surfDS.data(), (int32_t)surfDS.size(), pose, &idx), "lvi_keyframe_add");
+        return idx;
+    }
+    // … and extractCloud (:931-965) for the key indices extractNearby selected (cloudToExtract[i].intensity)
+    void extractCloud(const std::vector<int32_t>& keyInds)
+    {
+        check(lvi_map_assemble(h_.get(), keyInds.data(), (int32_t)keyInds.size()), "lvi_map_assemble");
+        haveMap_ = true;
+    }
     // downsampleCurrentScan + scan2MapOptimization; returns the soft status (LVI_OK, LVI_TOO_FEW_FEATURES, …)
     int32_t laserCloudInfoHandler(const CloudInfo& cloudInfo)
     {

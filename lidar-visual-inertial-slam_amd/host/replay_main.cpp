@@ -67,6 +67,57 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < ft.cur_pts.size(); i++) printf("%d %d %.9g %.9g\n", ft.ids[i], ft.track_cnt[i], ft.cur_pts[i].x, ft.cur_pts[i].y);
             return 0;
         }
+        if (argc >= 7 && !strcmp(argv[1], "extras")) {
+            // replay_main extras <Horizon_SCAN> <scan.bin> <n_raw> <w> <h> <img.bin>
+            // f-1 deskew through ImageProjection::imuDeskewInfo, f-4 keyframes + map assembly + matching against it,
+            // f-2 equalised readImage, f-3 undistortedPoints: the rows next to the path, through the host mirror
+            lvi_lidar_params P; lvi_lidar_params_default(&P);
+            P.Horizon_SCAN = atoi(argv[2]);
+            const int n_raw = atoi(argv[4]);
+            P.max_raw_points = n_raw + 16; P.max_map_points = 1 << 20;
+            LidarHandle h(P, 0);
+            auto scan = read_file<lvi_livox_pt>(argv[3], n_raw);
+            ImageProjection ip(h); FeatureExtraction fe(h); MapOptimization mo(h);
+            // a 200 Hz IMU turning at 0.5 rad/s about z, scan stamped at t = 100 s
+            std::vector<double> t, wx, wy, wz;
+            for (int i = 0; i < 40; i++) { t.push_back(99.99 + 0.005 * i); wx.push_back(0.0); wy.push_back(0.0); wz.push_back(0.5); }
+            const bool dk = ip.imuDeskewInfo(t.data(), wx.data(), wy.data(), wz.data(), (int)t.size(), 100.0, 100.1);
+            CloudInfo ci = ip.cloudHandler(scan.data(), n_raw, 100.0);
+            double sx = 0, sy = 0;
+            for (const lvi_pt& p : ci.cloud_deskewed) { sx += p.x; sy += p.y; }
+            printf("backend %s\ndeskew %d n %zu sum %.6f %.6f\n", lvi_backend(), (int)dk, ci.cloud_deskewed.size(), sx, sy);
+            ip.clearDeskew();
+            ci = ip.cloudHandler(scan.data(), n_raw, 100.0);
+            fe.laserCloudInfoHandler(ci);
+            // the scan becomes keyframe 0 (identity pose) and keyframe 1 (shifted by 0.05 m): the fused map is what the
+            // same scan is then matched against, starting 0.1 m off
+            const float pose0[6] = {0, 0, 0, 0, 0, 0}, pose1[6] = {0, 0, 0, 0.05f, 0, 0};
+            const int k0 = mo.saveKeyFrame(ci.cloud_corner, ci.cloud_surface, pose0);
+            const int k1 = mo.saveKeyFrame(ci.cloud_corner, ci.cloud_surface, pose1);
+            mo.extractCloud(std::vector<int32_t>{k0, k1});
+            mo.transformTobeMapped[3] = 0.1f;
+            const int st = mo.laserCloudInfoHandler(ci);
+            printf("keys %d %d status %d iters %d pose", k0, k1, st, mo.last.iters);
+            for (int k = 0; k < 6; k++) printf(" %.9g", mo.transformTobeMapped[k]);
+            printf("\n");
+            const int w = atoi(argv[5]), hgt = atoi(argv[6]);
+            lvi_tracker_params TP; lvi_tracker_params_default(&TP);
+            TP.max_width = w; TP.max_height = hgt; TP.max_cnt = 40; TP.min_dist = 12;
+            TrackerHandle th(TP, 0);
+            FeatureTracker ft(th, hgt, w, TP.max_cnt, (int)TP.min_dist);
+            ft.setEqualize(true);
+            const lvi_mei_params cam{1.9926618269451453, -0.0399258932468764, 0.15160828121223818, 0.00017756967825777937, -0.0011531239076798612,
+                                     669.8940458885896, 669.1450614220616, 0.5 * w, 0.5 * hgt};
+            ft.setCamera(cam);
+            auto img = read_file<uint8_t>(argv[7], (size_t)w * hgt);
+            ft.readImage(img.data(), 1.0);
+            for (unsigned i = 0; ft.updateID(i); i++) {}
+            ft.readImage(img.data(), 1.1);
+            printf("features %zu un %zu vel %zu\n", ft.cur_pts.size(), ft.cur_un_pts.size(), ft.pts_velocity.size());
+            for (size_t i = 0; i < ft.cur_pts.size(); i++)
+                printf("%.9g %.9g %.9g %.9g %.9g %.9g\n", ft.cur_pts[i].x, ft.cur_pts[i].y, ft.cur_un_pts[i].x, ft.cur_un_pts[i].y, ft.pts_velocity[i].x, ft.pts_velocity[i].y);
+            return 0;
+        }
         fprintf(stderr, "usage: see the header of replay_main.cpp\n");
         return 1;
     } catch (const std::exception& e) {

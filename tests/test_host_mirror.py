@@ -85,3 +85,50 @@ def test_filled_circle_is_a_disc(pkg, oracle, tmp_path):
         rad, area, sym, edge, outside = (int(v) for v in ln.split())
         assert sym == 1 and edge == 0 and outside == 255
         assert abs(area - np.pi * rad * rad) <= 4 * rad + 4
+
+
+def test_extras_through_the_host_mirror(pkg, oracle, replay_bin, tmp_path):
+    """f-1 … f-4 through lvi_host.hpp (imuDeskewInfo, saveKeyFrame / extractCloud(keys), setEqualize, undistortedPoints)
+    against the same calls made from Python"""
+    S = pkg.synth
+    scan = S.make_scan(8001, S.loop_pose(0.4), 21)
+    w, h = 240, 180
+    img = S.make_texture(w, h, 5)
+    scan.tofile(tmp_path / "scan.bin"); img.tofile(tmp_path / "img.bin")
+    r = subprocess.run([replay_bin, "extras", "4096", str(tmp_path / "scan.bin"), str(len(scan)), str(w), str(h), str(tmp_path / "img.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    # --- deskew: the host-side integration of the IMU samples equals the table built here
+    L = pkg.LidarHotpath(oracle, N_SCAN=4, Horizon_SCAN=4096, max_raw_points=9000, max_map_points=1 << 20)
+    tt = 99.99 + 0.005 * np.arange(40)
+    tt = tt[(tt >= 100.0 - 0.01) & (tt <= 100.1 + 0.01)]
+    rot = np.zeros((len(tt), 3)); rot[:, 2] = 0.5 * (tt - tt[0])
+    info = L.organize_scan_deskew(scan, 100.0, tt, rot)
+    f = lines[1].split()
+    assert f[0] == "deskew" and f[1] == "1" and int(f[3]) == info["n"]
+    xyz = np.stack([info["cloud_deskewed"]["x"], info["cloud_deskewed"]["y"]], axis=1).astype(np.float64)
+    np.testing.assert_allclose([float(f[5]), float(f[6])], xyz.sum(axis=0), rtol=0, atol=2e-2)
+    # --- keyframes + assembly + matching
+    plain = L.organize_scan(scan)
+    c, s = L.extract_features(plain)
+    assert L.keyframe_add(c, s, np.zeros(6, np.float32)) == 0
+    assert L.keyframe_add(c, s, np.array([0, 0, 0, 0.05, 0, 0], np.float32)) == 1
+    L.map_assemble([0, 1])
+    res = L.scan_to_map(c, s, np.array([0, 0, 0, 0.1, 0, 0], np.float32))
+    f = lines[2].split()
+    assert f[:3] == ["keys", "0", "1"] and int(f[4]) == res["status"] and int(f[6]) == res["iters"]
+    np.testing.assert_array_equal(np.array([float(v) for v in f[8:14]], np.float32), res["pose"])
+    assert abs(res["pose"][3] - 0.025) < 0.02                      # between the two copies of the scan
+    L.close()
+    # --- equalised tracking + undistortion + velocity
+    n = int(lines[3].split()[1])
+    assert n > 10 and lines[3].split()[3] == str(n) and lines[3].split()[5] == str(n)
+    rows = np.array([[float(v) for v in ln.split()] for ln in lines[4:4 + n]])
+    T = pkg.TrackerHotpath(oracle, max_width=w, max_height=h)
+    cam = dict(xi=1.9926618269451453, k1=-0.0399258932468764, k2=0.15160828121223818, p1=0.00017756967825777937, p2=-0.0011531239076798612,
+               gamma1=669.8940458885896, gamma2=669.1450614220616, u0=0.5 * w, v0=0.5 * h)
+    un = T.undistort_points(cam, rows[:, :2].astype(np.float32))
+    np.testing.assert_array_equal(un, rows[:, 2:4].astype(np.float32))
+    assert np.abs(rows[:, 4:6]).max() < 1e-3                       # the same image twice: tracked features do not move
+    T.close()
