@@ -132,3 +132,40 @@ def test_extras_through_the_host_mirror(pkg, oracle, replay_bin, tmp_path):
     np.testing.assert_array_equal(un, rows[:, 2:4].astype(np.float32))
     assert np.abs(rows[:, 4:6]).max() < 1e-3                       # the same image twice: tracked features do not move
     T.close()
+
+
+@pytest.mark.gpu
+def test_cpp_host_over_the_hip_library(pkg, oracle, hip, tmp_path):
+    """the same C++ host code linked with liblvi_hip.so (no Python between the node-side classes and the kernels)"""
+    out = tmp_path / "replay_hip"
+    src = os.path.join(pkg.PKG_DIR, "host", "replay_main.cpp")
+    hdir = os.path.dirname(pkg.HIP_LIB_PATH)
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(out), src, "-L" + hdir, "-llvi_hip", "-Wl,-rpath," + hdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sc = make_small_scene(pkg, oracle, n_raw=8001, n_kf=6, Horizon_SCAN=4096)
+    sc["scan"].tofile(tmp_path / "scan.bin"); sc["map_corner"].tofile(tmp_path / "mc.bin"); sc["map_surf"].tofile(tmp_path / "ms.bin")
+    args = [str(out), "lidar", "4096", str(tmp_path / "scan.bin"), str(len(sc["scan"])), str(tmp_path / "mc.bin"), str(len(sc["map_corner"])),
+            str(tmp_path / "ms.bin"), str(len(sc["map_surf"]))] + ["%.9g" % v for v in sc["guess"]]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("backend hip")
+    pose_cpp = np.array([float(v) for v in lines[-1].split()[1:]], np.float32)
+    h = pkg.LidarHotpath(oracle, **small_params(Horizon_SCAN=4096, max_raw_points=9000, max_map_points=400000))
+    h.map_set(sc["map_corner"], sc["map_surf"])
+    info = h.organize_scan(sc["scan"])
+    c, s = h.extract_features(info)
+    res = h.scan_to_map(c, s, sc["guess"])
+    h.close()
+    assert f"corner {len(c)} surf {len(s)}" in r.stdout
+    dp = np.abs(pose_cpp - res["pose"])
+    assert dp[:3].max() < 1e-4 and dp[3:].max() < 1e-4
+    # the rows next to the path through the same binary
+    S = pkg.synth
+    img = S.make_texture(240, 180, 5)
+    img.tofile(tmp_path / "img.bin")
+    r = subprocess.run([str(out), "extras", "4096", str(tmp_path / "scan.bin"), str(len(sc["scan"])), "240", "180", str(tmp_path / "img.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[1].split()[1] == "1" and lines[2].split()[4] == "0" and int(lines[3].split()[1]) > 10
