@@ -336,7 +336,8 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
     // in its greedy walks; what s+1 needs from s — the marks on its first five points — arrives in ONE device-scope
     // atomic word (5 flag bits + a ready bit), so no memory fence (= L2 write-back on this multi-XCD part) is involved.
     // Workgroups are dispatched in blockIdx order, a producer always before its consumer, and a ring needs 6 of the
-    // 256 CUs, so a waiting consumer can never keep its producer from running.  Rings with a degenerate sector
+    // 256 CUs, so a waiting consumer can never keep its producer from running (as long as all such workgroups in
+    // flight fit the chip: hence the 4-ring limit below; a bounded spin turns a lost hand-over into an error).  Rings with a degenerate sector
     // (< 66 points) take the sequential form: the sector-0 workgroup walks all six (carry through LDS, as before).
     const int ring = blockIdx.x / 6, my_sec = blockIdx.x % 6;
     const int n = *a.d_n;
@@ -375,7 +376,9 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
             pf_fl[i] = in ? a.pflags[k] : (uint8_t)3;
         }
     };
-    bool piped = true;
+    // pipelined only for up to 4 rings (24 workgroups, each owning a CU's LDS): with many more, several such kernels in flight
+    // from different streams could fill every CU with waiting consumers while their producers still wait for a CU
+    bool piped = a.N_SCAN * 6 <= 24;
     for (int q = 0; q < 6; q++) { int sp_, ep_; piped = piped && bounds(q, sp_, ep_); }
     if (!piped && my_sec != 0) return;
     const int sec_begin = piped ? my_sec : 0, sec_end = piped ? my_sec + 1 : 6;
