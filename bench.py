@@ -136,6 +136,22 @@ def main():
             h.sync()
     cnt_map = g.counts()
 
+    # ---------------------------------------------------------------- measured copy ceiling of this GPU (report % of the vendor
+    # figure AND of a measured device copy): 256 MB float4 tensor copied device-to-device, bytes read + written / time
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty((16 * 1024 * 1024, 4), dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbs = round(10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del src, dst
+
     # ---------------------------------------------------------------- scan pool of this rank, resident in HBM
     poses, guesses, scans_host, d_scans = [], [], [], []
     for k in range(args.pool):
@@ -278,6 +294,7 @@ def main():
         cand = [v["hbm_bytes_per_launch"] for k, v in traffic_tab.items() if k.startswith(base + " ")]
         tr = max(cand) if cand else None
         return dict(bound="hbm", kernel=s["name"], achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                    measured_copy_gbs=copy_gbs, frac_of_measured_copy=(round(gbs / copy_gbs, 4) if copy_gbs else None),
                     traffic=tr, bytes_alg_per_launch=b, avg_launch_us=round(s["avg_us"], 2), launches_per_scan=s["launches"] / max(args.profile_steps, 1),
                     note=note)
 
