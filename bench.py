@@ -362,6 +362,22 @@ def main():
                                    sample="%d scans of the same workload after 2 warm-up scans (%.1f s), CPU restatement of the reference "
                                           "(oracle/), OpenMP num_threads(8) only on the four loops the reference parallelises" % (len(times), sum(times)))
         out["speedup_vs_cpu"] = round(out["value"] / cpu_rate, 1)
+        if isinstance(out.get("tracker"), dict) and "value" in out["tracker"]:
+            # the same LK step on the oracle (scalar, single-threaded restatement of OpenCV's calcOpticalFlowPyrLK; a real
+            # OpenCV build would use SIMD and its thread pool — SURVEY 8d caveat)
+            S = pkg.synth
+            w, h = 1280, 720
+            img0 = S.make_texture(w, h, 4242)
+            img1 = S.warp_homography(img0, S.small_motion_homography(w, h, 100))
+            ot = pkg.TrackerHotpath(ora, max_width=w, max_height=h)
+            pts = ot.good_features(img0, 150, 0.01, 20.0)
+            ot.push_image(img0)
+            t1 = time.perf_counter()
+            nfr = 4
+            for i in range(nfr):
+                ot.push_image(img1 if i % 2 == 0 else img0); ot.set_points(pts); ot.run_lk()
+            out["tracker"]["cpu_oracle_frames_per_sec"] = round(nfr / (time.perf_counter() - t1), 2)
+            ot.close()
 
     if rank == 0:
         print(json.dumps(out), flush=True)
