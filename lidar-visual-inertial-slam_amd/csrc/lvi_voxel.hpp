@@ -123,7 +123,8 @@ struct VoxelPlan {
 //           accumulates its voxels in LDS; ~2.5x less HBM traffic and 8 launches instead of 19 when the grid is
 //           compact (div_b product <= VB_NB << VB_CL_LOG); still correct, but sweeping each bin several times,
 //           when it is not.
-// AUTO enqueues BINNED when the previous run's grids (read from pinned host memory, no sync) were compact.  d_dyn must have been written (on the same
+// AUTO enqueues BINNED when the previous run's grids (read from pinned host memory, no sync) had at most
+// 16.8 M cells (four sweeps per bin), SORTED for sparser ones.  d_dyn must have been written (on the same
 // stream) by the producer.  n_hint: nominal total input points, for byte accounting only.
 void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& plan, const char* tag, double n_hint);
 
