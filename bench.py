@@ -46,6 +46,8 @@ def parse():
                          "device-resident keyframe store (SURVEY f-4: what a node does instead of uploading 78 MB per scan)")
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--pool", type=int, default=8, help="distinct scans per rank, cycled")
+    ap.add_argument("--queue-depth", type=int, default=2,
+                    help="scans kept enqueued per handle in the rolling form (1 = sync a handle before its next scan)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="independent scans in flight per GPU (BASELINE config 5: batched replay); each has its own handle, "
                          "streams and map replica; a step processes this many scans per rank")
@@ -171,7 +173,8 @@ def main():
     enq = [0.0]
 
     rolling = args.enqueue in ("eager", "threads") and not args.step_sync
-    pending = [None]          # rolling mode: index of the step whose records have not been gathered yet
+    depth = max(1, min(args.queue_depth, 8))
+    pending = []              # rolling mode: steps whose records have not been gathered yet
 
     def step(i):
         t_e = time.perf_counter()
@@ -182,7 +185,9 @@ def main():
             h = hs[b]
             k = (i * B + b) % args.pool
             if rolling:
-                h.sync()                                                  # its scan of step i-1 is complete
+                # at most --queue-depth scans enqueued per handle: wait for the one issued `depth` steps ago (depth 1 = the
+                # handle is idle while the host prepares its next scan; depth 2 keeps its queue fed)
+                h.wait_mark(i % depth)
             if args.enqueue == "graph":
                 # one C-ABI call per scan: D2D of the 2 MB scan + one hipGraph launch of the whole path
                 h.scan_replay_enqueue(d_scans[k].data_ptr(), args.n_raw, guesses[k], d_rec[i * B + b].data_ptr(), rebuild_map=not args.frozen_map)
@@ -195,6 +200,8 @@ def main():
                 h.scan_upload_device(d_scans[k].data_ptr(), args.n_raw)   # D2D, 2 MB
                 h.scan_organize(); h.scan_extract(); h.scan_downsample()
                 h.scan_match_async(guesses[k], d_rec[i * B + b].data_ptr())
+            if rolling:
+                h.mark(i % depth)
             if args.enqueue == "threads" and not rolling:
                 h.sync()
         if args.enqueue == "threads" and B > 1:
@@ -204,10 +211,12 @@ def main():
                 one(b)
         enq[0] += time.perf_counter() - t_e
         if rolling:
-            # every handle was synchronised above before its new scan went in: the records of step i-1 are final
-            j, pending[0] = pending[0], i
-            if world > 1 and j is not None:
-                pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
+            # every handle waited above for its scan of step i-depth before the new one went in: those records are final
+            pending.append(i)
+            if len(pending) > depth:
+                j = pending.pop(0)
+                if world > 1:
+                    pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
             return
         for h in hs:
             h.sync()
@@ -218,9 +227,10 @@ def main():
         """rolling mode: finish the step still in flight and gather its records (inside the timed region)"""
         for h in hs:
             h.sync()
-        j, pending[0] = pending[0], None
-        if rolling and world > 1 and j is not None:
-            pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
+        while pending:
+            j = pending.pop(0)
+            if rolling and world > 1:
+                pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
 
     def fence():
         torch.cuda.synchronize()
@@ -322,7 +332,7 @@ def main():
                     if not args.frozen_map else "lidar_odometry scan-to-map with a frozen downsampled map (DS + index reused)",
                     n_raw=args.n_raw, map_raw_points=nc + ns, map_ds_points=cnt_map["map_corner_ds"] + cnt_map["map_surf_ds"],
                     scan_features=dict(corner=cnt["corner"], surf=cnt["surf"], corner_ds=cnt["corner_ds"], surf_ds=cnt["surf_ds"]),
-                    icp_iters=args.icp_iters, map_source=args.map_source, scans_in_flight_per_gpu=B, scans_per_step=world * B, enqueue=args.enqueue,
+                    icp_iters=args.icp_iters, map_source=args.map_source, scans_in_flight_per_gpu=B, scans_per_step=world * B, enqueue=args.enqueue, queue_depth=(depth if rolling else 1),
                     handle_sync="per step" if not rolling else "per handle, before it is reused",
                     sharding="independent scans sharded across ranks (B in flight per rank), RCCL all_gather of pose records per step"),
         roofline=roofline, roofline_streaming_kernel=roofline_bw,

@@ -167,6 +167,12 @@ void    lvi_lidar_params_default(lvi_lidar_params *p);      /* values of params_
 int32_t lvi_lidar_create(const lvi_lidar_params *p, int32_t device, lvi_lidar **out);
 void    lvi_lidar_destroy(lvi_lidar *h);
 int32_t lvi_lidar_sync(lvi_lidar *h);                       /* wait for the handle's stream */
+/* queue depth > 1: lvi_lidar_mark records a point in the handle's stream order (after everything enqueued so far),
+ * lvi_lidar_wait_mark blocks the caller until that point has been reached; a slot never marked returns at once.
+ * A replayer keeps D scans enqueued per handle by marking slot i % D after scan i and waiting on it before scan i + D. */
+#define LVI_LIDAR_MARKS 8
+int32_t lvi_lidar_mark(lvi_lidar *h, int32_t slot);
+int32_t lvi_lidar_wait_mark(lvi_lidar *h, int32_t slot);
 
 /* ---- one-call entry points with host buffers (a maintainer's drop-in seams) */
 

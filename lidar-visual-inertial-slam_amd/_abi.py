@@ -104,6 +104,8 @@ SIGNATURES = {
     "lvi_lidar_create": (_i32, [_P(LidarParams), _i32, _P(_vp)]),
     "lvi_lidar_destroy": (None, [_vp]),
     "lvi_lidar_sync": (_i32, [_vp]),
+    "lvi_lidar_mark": (_i32, [_vp, _i32]),
+    "lvi_lidar_wait_mark": (_i32, [_vp, _i32]),
     "lvi_organize_scan": (_i32, [_vp, _vp, _i32, _P(ScanInfo)]),
     "lvi_extract_features": (_i32, [_vp, _P(ScanInfo), _P(Cloud), _P(Cloud)]),
     "lvi_voxel_downsample": (_i32, [_vp, _vp, _i32, _f32, _vp, _i32, _P(_i32)]),

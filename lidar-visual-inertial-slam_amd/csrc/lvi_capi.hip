@@ -215,6 +215,7 @@ void lvi_lidar_destroy(lvi_lidar* h)
     if (h->d.graphExec) (void)hipGraphExecDestroy(h->d.graphExec);
     if (h->d.ctx.stream) (void)hipStreamDestroy(h->d.ctx.stream);
     if (h->d.ctx2.stream) (void)hipStreamDestroy(h->d.ctx2.stream);
+    for (int s = 0; s < LVI_LIDAR_MARKS; s++) if (h->d.evMark[s]) (void)hipEventDestroy(h->d.evMark[s]);
     if (h->d.evMain) (void)hipEventDestroy(h->d.evMain);
     if (h->d.evMap) (void)hipEventDestroy(h->d.evMap);
     delete h;
@@ -224,6 +225,29 @@ int32_t lvi_lidar_sync(lvi_lidar* h)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
     return guarded(h, [&]() -> int32_t { sync(h->d); return LVI_OK; });
+}
+
+int32_t lvi_lidar_mark(lvi_lidar* h, int32_t slot)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    if (slot < 0 || slot >= LVI_LIDAR_MARKS) return fail(LVI_ERR_INVALID_ARG, "mark slot out of range");
+    return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        if (!d.evMark[slot]) LVI_HIP(hipEventCreateWithFlags(&d.evMark[slot], hipEventDisableTiming));
+        join_map(d);                                       // a map build still on its own stream is part of "everything enqueued so far"
+        LVI_HIP(hipEventRecord(d.evMark[slot], d.ctx.stream));
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_lidar_wait_mark(lvi_lidar* h, int32_t slot)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    if (slot < 0 || slot >= LVI_LIDAR_MARKS) return fail(LVI_ERR_INVALID_ARG, "mark slot out of range");
+    return guarded(h, [&]() -> int32_t {
+        if (h->d.evMark[slot]) LVI_HIP(hipEventSynchronize(h->d.evMark[slot]));
+        return LVI_OK;
+    });
 }
 
 // ---- staged form ------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ struct LidarDev {
     Ctx ctx;                                               // scan-side stages and the GN loop
     Ctx ctx2;                                              // map build (independent of the scan until scan matching)
     hipEvent_t evMain = nullptr, evMap = nullptr;
+    hipEvent_t evMark[LVI_LIDAR_MARKS] = {};               // lvi_lidar_mark / lvi_lidar_wait_mark, created on first use
     bool map_pending = false;                              // map build enqueued on ctx2, not yet joined by ctx
     Profiler prof;
     Arena arena;

@@ -223,6 +223,14 @@ class LidarHotpath:
     def sync(self):
         self.lib.check(self.lib.dll.lvi_lidar_sync(self._h), "lvi_lidar_sync")
 
+    def mark(self, slot):
+        """record a point in the handle's stream order (everything enqueued so far)"""
+        self.lib.check(self.lib.dll.lvi_lidar_mark(self._h, int(slot)), "lvi_lidar_mark")
+
+    def wait_mark(self, slot):
+        """block until the point recorded by mark(slot) has been reached (at once if never marked)"""
+        self.lib.check(self.lib.dll.lvi_lidar_wait_mark(self._h, int(slot)), "lvi_lidar_wait_mark")
+
     def get_scan_info(self):
         si, bufs = self._new_scan_info()
         self.lib.check(self.lib.dll.lvi_get_scan_info(self._h, C.byref(si)), "lvi_get_scan_info")

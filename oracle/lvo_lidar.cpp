@@ -774,6 +774,8 @@ int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t /*device*/, lvi_lida
 }
 void lvi_lidar_destroy(lvi_lidar* h) { delete h; }
 int32_t lvi_lidar_sync(lvi_lidar*) { return LVI_OK; }
+int32_t lvi_lidar_mark(lvi_lidar* h, int32_t slot) { return (h && slot >= 0 && slot < LVI_LIDAR_MARKS) ? LVI_OK : fail(LVI_ERR_INVALID_ARG, "bad mark"); }
+int32_t lvi_lidar_wait_mark(lvi_lidar* h, int32_t slot) { return (h && slot >= 0 && slot < LVI_LIDAR_MARKS) ? LVI_OK : fail(LVI_ERR_INVALID_ARG, "bad mark"); }
 
 int32_t lvi_scan_upload(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw)
 {

@@ -470,6 +470,63 @@ def test_map_on_main_stream_gives_identical_results(pkg, hip, scene):
     np.testing.assert_array_equal(res[0][2].view(np.uint32), res[1][2].view(np.uint32))
 
 
+def test_queue_depth_two_gives_the_same_records(pkg, hip, scene):
+    """lvi_lidar_mark / lvi_lidar_wait_mark: scans enqueued back to back without a host sync (depth 2, either map
+    stream) write the same pose records as scan-by-scan with lvi_lidar_sync"""
+    import ctypes as C
+    rt = C.CDLL("libamdhip64.so.7")                          # the runtime liblvi_hip.so is linked against (torch brings its own copy)
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+
+    def dev_alloc(nbytes):
+        p = C.c_void_p()
+        assert rt.hipMalloc(C.byref(p), nbytes) == 0
+        return p
+
+    S = pkg.synth
+    scans = [S.make_scan(12000, S.loop_pose(0.3 + 0.5 * k, 0.0, 0.0), 400 + k) for k in range(4)]
+    guesses = [S.perturbed_guess(S.loop_pose(0.3 + 0.5 * k, 0.0, 0.0), 50 + k) for k in range(4)]
+    d_scans = []
+    for sc in scans:
+        buf = np.ascontiguousarray(sc)
+        p = dev_alloc(buf.nbytes)
+        assert rt.hipMemcpy(p, buf.ctypes.data, buf.nbytes, H2D) == 0
+        d_scans.append(p)
+    d_rec = dev_alloc(len(scans) * 32)
+    out = []
+    for depth, stream_mode in ((1, 0), (2, 0), (2, 1)):
+        g = pkg.LidarHotpath(hip, map_on_main_stream=stream_mode, **small_params())
+        g.map_upload(scene["map_corner"], scene["map_surf"])
+        zero = np.zeros((len(scans), 8), np.float32)
+        assert rt.hipMemcpy(d_rec, zero.ctypes.data, zero.nbytes, H2D) == 0
+        for i in range(len(scans)):
+            if depth == 1:
+                g.sync()
+            else:
+                g.wait_mark(i % depth)
+            g.map_build()
+            g.scan_upload_device(d_scans[i].value, len(scans[i]))
+            g.scan_organize(); g.scan_extract(); g.scan_downsample()
+            g.scan_match_async(guesses[i], d_rec.value + 32 * i)
+            g.mark(i % depth)
+        for s in range(depth):
+            g.wait_mark(s)
+        g.wait_mark(7)                                     # never marked: returns at once
+        rec = np.zeros((len(scans), 8), np.float32)        # no lvi_lidar_sync before this read: the marks alone cover it
+        assert rt.hipMemcpy(rec.ctypes.data, d_rec, rec.nbytes, D2H) == 0
+        out.append(rec)
+        with pytest.raises(Exception):
+            g.mark(8)
+        g.sync(); g.close()
+    for p in d_scans + [d_rec]:
+        rt.hipFree(p)
+    assert (out[0][:, 6].view(np.int32) == 0).all()
+    np.testing.assert_array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+    np.testing.assert_array_equal(out[0].view(np.uint32), out[2].view(np.uint32))
+
+
 def test_parity_sweep_over_scans_and_settings(pkg, oracle, hip, scene):
     """the whole path on a dozen different scans / poses / thresholds: selected indices exact, poses within the bar"""
     S = pkg.synth
@@ -546,7 +603,7 @@ def test_replay_enqueue_matches_staged_path(pkg, oracle, hip, scene):
         h.map_upload(scene["map_corner"], scene["map_surf"])
     # the replay entry point wants the scan in device memory: borrow the handle g's own raw buffer through a
     # second handle's upload → not available from Python, so stage it via hipMalloc from the HIP runtime
-    hiprt = C.CDLL("libamdhip64.so")
+    hiprt = C.CDLL("libamdhip64.so.7")
     for rep in range(3):                         # first call captures, later calls replay the graph
         for sc, gs in zip(scans, guesses):
             o.map_build(); o.scan_upload(sc); o.scan_organize(); o.scan_extract(); o.scan_downsample()
