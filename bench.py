@@ -333,7 +333,7 @@ def main():
                     n_raw=args.n_raw, map_raw_points=nc + ns, map_ds_points=cnt_map["map_corner_ds"] + cnt_map["map_surf_ds"],
                     scan_features=dict(corner=cnt["corner"], surf=cnt["surf"], corner_ds=cnt["corner_ds"], surf_ds=cnt["surf_ds"]),
                     icp_iters=args.icp_iters, map_source=args.map_source, scans_in_flight_per_gpu=B, scans_per_step=world * B, enqueue=args.enqueue, queue_depth=(depth if rolling else 1),
-                    handle_sync="per step" if not rolling else "per handle, before it is reused",
+                    handle_sync="per step" if not rolling else "per handle: before enqueueing a scan, wait for the one issued queue_depth steps earlier",
                     sharding="independent scans sharded across ranks (B in flight per rank), RCCL all_gather of pose records per step"),
         roofline=roofline, roofline_streaming_kernel=roofline_bw,
         results_ok=ok, pose_err_vs_truth=dict(trans_m=err_t, rot_rad=err_r),
