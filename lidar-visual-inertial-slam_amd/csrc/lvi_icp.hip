@@ -600,15 +600,18 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
 __device__ void make_pose(IcpPose& p)
 {
     // pcl::getTransformation(x,y,z,roll,pitch,yaw) (trans2Affine3f :404-407)
-    const float roll = p.T[0], pitch = p.T[1], yaw = p.T[2];
-    const float A = cosf(yaw), B = sinf(yaw), C = cosf(pitch), D = sinf(pitch), E = cosf(roll), F = sinf(roll), DE = D * E, DF = D * F;
+    // sinf / cosf of the host (glibc: correctly rounded but for rare cases) are matched by rounding the double result;
+    // the device's own float versions are 1-2 ulp off, enough to move a point across a selection threshold
+    double sr, cr, sp, cp, sy, cy;
+    sincos((double)p.T[0], &sr, &cr); sincos((double)p.T[1], &sp, &cp); sincos((double)p.T[2], &sy, &cy);
+    const float A = (float)cy, B = (float)sy, C = (float)cp, D = (float)sp, E = (float)cr, F = (float)sr, DE = D * E, DF = D * F;
     p.A[0] = A * C; p.A[1] = A * DF - B * E; p.A[2] = B * F + A * DE; p.A[3] = p.T[3];
     p.A[4] = B * C; p.A[5] = A * E + B * DF; p.A[6] = B * DE - A * F; p.A[7] = p.T[4];
     p.A[8] = -D;    p.A[9] = C * F;          p.A[10] = C * E;         p.A[11] = p.T[5];
     // LMOptimization :1202-1207 — srx from pitch, sry from yaw, srz from roll
-    p.trig[0] = sinf(p.T[1]); p.trig[1] = cosf(p.T[1]);
-    p.trig[2] = sinf(p.T[2]); p.trig[3] = cosf(p.T[2]);
-    p.trig[4] = sinf(p.T[0]); p.trig[5] = cosf(p.T[0]);
+    p.trig[0] = D; p.trig[1] = C;
+    p.trig[2] = B; p.trig[3] = A;
+    p.trig[4] = F; p.trig[5] = E;
 }
 
 __global__ void set_pose_init_kernel(float* dst, float t0, float t1, float t2, float t3, float t4, float t5)
