@@ -136,6 +136,19 @@ def main():
             for h in (o2, g2):
                 h.map_set(mc, ms)
             so, sg = o2.scan_to_map(fc, fs, p0), g2.scan_to_map(fc, fs, p0)
+            if detail is not None:
+                jo, jg = o2.debug_get(A.DBG_ICP_JTJ, np.float32).reshape(-1, 27), g2.debug_get(A.DBG_ICP_JTJ, np.float32).reshape(-1, 27)
+                to, tg = o2.debug_get(A.DBG_ICP_POSE_TRACE, np.float32).reshape(-1, 6), g2.debug_get(A.DBG_ICP_POSE_TRACE, np.float32).reshape(-1, 6)
+                np.set_printoptions(linewidth=250, precision=9)
+                for it in range(min(so["iters"], sg["iters"])):
+                    print(" iter", it, "pose o", to[it], "\n         pose g", tg[it], "\n   |d pose|", np.abs(to[it] - tg[it]))
+                    print("   JtJ/Jtb words that differ:", int((jo[it].view(np.uint32) != jg[it].view(np.uint32)).sum()), "max rel", float(np.max(np.abs(jo[it] - jg[it]) / (np.abs(jo[it]) + 1e-30))))
+                    if it == 0:
+                        M = np.zeros((6, 6)); k = 0
+                        for r_ in range(6):
+                            for c_ in range(r_, 6):
+                                M[r_, c_] = M[c_, r_] = jo[it][k]; k += 1
+                        w = np.linalg.eigvalsh(M); print("   eig(JtJ)", w, "cond", w[-1] / w[0])
             o2.close(); g2.close()
             seam_diff = float(np.abs(so["pose"] - sg["pose"]).max())
             seam_ok = so["status"] == sg["status"] and so["iters"] == sg["iters"] and (so["status"] != 0 or seam_diff < 1e-4)
