@@ -497,7 +497,8 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
     const int cell = filter ? (int)rint(a.min_dist) : 1;
     const double md2 = a.min_dist * a.min_dist;
     int nacc = 0;
-    const int limit = (a.max_corners > 0) ? min(a.max_corners, a.cap) : a.cap;
+    // one corner past the capacity is enough to know the result does not fit (it is counted, not stored)
+    const int limit = (a.max_corners > 0) ? min(a.max_corners, a.cap + 1) : a.cap + 1;
     bool overflow = false;
     for (int base = 0; base < total && nacc < limit; base += 64) {
         const int i = base + l;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
             const int fx = __shfl(x, first, 64), fy = __shfl(y, first, 64), fxc = __shfl(xc, first, 64), fyc = __shfl(yc, first, 64);
             if (l == first) {
                 if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; acx[nacc] = (short)xc; acy[nacc] = (short)yc; }
-                a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y;
+                if (nacc < a.cap) { a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y; }
                 alive = false;
             }
             nacc++;
@@ -877,7 +878,7 @@ int32_t lvi_tracker_run_gftt(lvi_tracker* t, int32_t max_corners)
         LVI_HIP(hipMemcpyAsync(&res[1], t->d_ncand, sizeof(int), hipMemcpyDeviceToHost, t->ctx.stream));
         LVI_HIP(hipStreamSynchronize(t->ctx.stream));
         if (res[0] < 0) return tfail(LVI_ERR_CAPACITY, "more corners than the pick kernel's accepted-list capacity");
-        if (max_corners <= 0 && res[0] >= t->P.max_features) return tfail(LVI_ERR_CAPACITY, "more corners than max_features");
+        if (res[0] > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "more corners than max_features");
         t->gftt_n = res[0]; t->gftt_ncand = res[1]; t->have_gftt = true;
         return LVI_OK;
     });

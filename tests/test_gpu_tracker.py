@@ -65,6 +65,28 @@ def test_gftt_mask_quota_and_small_distance(pkg, pair, frames):
             assert len(pg) <= quota
 
 
+def test_gftt_capacity_rule_is_the_same_on_both_sides(pkg, oracle, hip, frames):
+    """a result that fits max_features exactly is returned; one corner more is LVI_ERR_CAPACITY — for an unlimited
+    quota and for a quota above the capacity alike"""
+    A = pkg._abi
+    big = pkg.TrackerHotpath(hip, max_width=640, max_height=480, max_features=1024)
+    ref = big.good_features(frames["img0"], 0, 0.01, 20.0)
+    big.close()
+    n = len(ref)
+    assert 40 < n < 1000
+    for lib in (oracle, hip):
+        fit = pkg.TrackerHotpath(lib, max_width=640, max_height=480, max_features=n)
+        np.testing.assert_array_equal(fit.good_features(frames["img0"], 0, 0.01, 20.0), ref)
+        np.testing.assert_array_equal(fit.good_features(frames["img0"], n + 5, 0.01, 20.0), ref)
+        fit.close()
+        tight = pkg.TrackerHotpath(lib, max_width=640, max_height=480, max_features=n - 1)
+        for quota in (0, n + 5):
+            with pytest.raises(A.LviError):
+                tight.good_features(frames["img0"], quota, 0.01, 20.0)
+        np.testing.assert_array_equal(tight.good_features(frames["img0"], n - 1, 0.01, 20.0), ref[:n - 1])
+        tight.close()
+
+
 def test_lk_bit_exact_and_tracks_the_motion(pkg, pair, frames):
     S = pkg.synth
     o, g = pair
