@@ -215,6 +215,24 @@ def test_voxel_downsample_keys_bit_exact(pkg, pair):
     _voxel_case(pkg, o, g, -np.abs(c), 0.2)
 
 
+def test_voxel_million_point_segments(pkg, oracle, hip):
+    """segments of a million points and more (many tiles per bin, multi-chunk bins, vb_merge): keys, cells, counts and
+    centroids as the oracle, identical bits from the binned and the sorted path"""
+    kw = dict(N_SCAN=4, Horizon_SCAN=1000, max_raw_points=4096, max_map_points=1400000)
+    o = pkg.LidarHotpath(oracle, **kw)
+    gb, gs = pkg.LidarHotpath(hip, voxel_mode=2, **kw), pkg.LidarHotpath(hip, voxel_mode=1, **kw)
+    rng = np.random.default_rng(8)
+    for n in ((1 << 20) - 1, 1 << 20, 1300007):
+        pts = np.zeros((n, 4), np.float32)
+        t = np.sort(rng.uniform(0, 1, n))                  # scan-line order with jumps, as a fused keyframe map
+        pts[:, 0] = 60 * np.cos(40 * t) * rng.uniform(0.2, 1, n); pts[:, 1] = 60 * np.sin(40 * t) * rng.uniform(0.2, 1, n)
+        pts[:, 2] = rng.uniform(-2, 6, n); pts[:, 3] = rng.uniform(0, 255, n)
+        _voxel_case(pkg, o, gb, pts, 0.4)
+        vb, vs = gb.voxel_downsample(pts, 0.4), gs.voxel_downsample(pts, 0.4)
+        np.testing.assert_array_equal(xyzi(vb).view(np.uint32), xyzi(vs).view(np.uint32))
+    o.close(); gb.close(); gs.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["vox_auto", "vox_sorted", "vox_binned"])
 def test_voxel_modes_ragged_sizes_and_sparse_grids(pkg, oracle, hip, mode):
     """ragged sizes around the wave / tile boundaries, compact grids (1024-voxel bins), sparse huge grids (wide bins
