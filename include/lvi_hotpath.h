@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LVI_ABI_VERSION 4
+#define LVI_ABI_VERSION 5
 
 /* ---- status codes -------------------------------------------------------- */
 #define LVI_OK                        0
@@ -96,7 +96,15 @@ typedef struct lvi_lidar_params {
      * scan in flight (0.88 vs 1.00 ms).  1: everything on the handle's main stream — best when >= 4 handles are in flight,
      * one stream per hardware queue (HIP's default is 4): 2 150 vs 2 030 scans/s.  Only the HIP backend reads it. */
     int32_t map_on_main_stream;
+    /* The sector kernel runs the six sectors of a ring as a pipeline of workgroups; a workgroup that has not received its
+     * predecessor's hand-over word after this many microseconds walks the ring from sector 0 itself (same results, no
+     * workgroup ever depends on another one being resident).  0 = default (2000), < 0 = never wait (tests).  HIP backend only. */
+    int32_t sector_handover_wait_us;
+    /* Capacity of the batched entry points (lvi_scan_batch_*): scans processed side by side by ONE launch sequence, every
+     * kernel carrying the scan index in blockIdx.z.  1 (default) = no batch slots beyond the handle's own. <= LVI_MAX_BATCH. */
+    int32_t batch_scans;
 } lvi_lidar_params;
+#define LVI_MAX_BATCH 8
 
 /* CloudInfo.msg:4-8 arrays + cloud_deskewed, as plain caller-owned arrays.
  * capacity = number of elements the three per-point arrays can hold. */
@@ -226,6 +234,12 @@ int32_t lvi_keyframes_clear(lvi_lidar *h);
 /* extractCloud for the keys in the given order (duplicates allowed, as the reference's list may hold them) followed by the
  * two map VoxelGrids and the index build: equivalent to lvi_map_set(fused corner, fused surf). */
 int32_t lvi_map_assemble(lvi_lidar *h, const int32_t *key_indices, int32_t n_keys);
+/* The same local map — laserCloud{Corner,Surf}FromMapDS and the search index, bit for bit what lvi_map_assemble(keys)
+ * returns — maintained incrementally: consecutive scans share almost all keyframes (extractNearby :894-929), so only the
+ * keyframes that enter or leave the list are added to / taken from persistent per-voxel sums; nothing re-reads the millions
+ * of points of the keyframes that stay.  A changed pose of a listed key (lvi_keyframe_set_pose), a duplicate in the list or
+ * PCL's overflow rule falls back to the full assembly.  The raw fused clouds (LVI_DBG_MAP_*_RAW) are not produced. */
+int32_t lvi_map_update(lvi_lidar *h, const int32_t *key_indices, int32_t n_keys);
 int32_t lvi_scan_organize(lvi_lidar *h);                                         /* a-0 (+ f-1 when a deskew table is set) */
 /* f-1: rotation table for the NEXT lvi_scan_organize calls (copied; NULL or imu_available == 0 switches deskew off). */
 int32_t lvi_scan_set_deskew(lvi_lidar *h, const lvi_deskew_info *info);

@@ -47,7 +47,8 @@ class LidarParams(C.Structure):
                 ("z_tollerance", C.c_float), ("rotation_tollerance", C.c_float), ("imuRPYWeight", C.c_float),
                 ("numberOfCores", C.c_int32), ("icp_max_iters", C.c_int32), ("icp_disable_break", C.c_int32),
                 ("max_raw_points", C.c_int32), ("max_map_points", C.c_int32), ("voxel_mode", C.c_int32),
-                ("max_keyframes", C.c_int32), ("max_keyframe_points", C.c_int32), ("map_on_main_stream", C.c_int32)]
+                ("max_keyframes", C.c_int32), ("max_keyframe_points", C.c_int32), ("map_on_main_stream", C.c_int32),
+                ("sector_handover_wait_us", C.c_int32), ("batch_scans", C.c_int32)]
 
 
 class ScanInfo(C.Structure):
@@ -121,6 +122,7 @@ SIGNATURES = {
     "lvi_keyframe_count": (_i32, [_vp, _P(_i32), _P(_i32)]),
     "lvi_keyframes_clear": (_i32, [_vp]),
     "lvi_map_assemble": (_i32, [_vp, _P(_i32), _i32]),
+    "lvi_map_update": (_i32, [_vp, _P(_i32), _i32]),
     "lvi_organize_scan_deskew": (_i32, [_vp, _vp, _i32, _vp, _P(ScanInfo)]),
     "lvi_scan_extract": (_i32, [_vp]),
     "lvi_scan_downsample": (_i32, [_vp]),

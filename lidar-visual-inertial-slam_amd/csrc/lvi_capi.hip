@@ -105,7 +105,10 @@ int read_int(LidarDev& d, const int* p)
 
 int32_t check_dev_status(LidarDev& d)
 {
-    const int st = read_int(d, d.d_status);
+    int w[2] = {0, 0};
+    d2h(d, w, d.d_status, 2);
+    sync(d);
+    const int st = w[0] | w[1];
     if (st & DEV_ERR_SECTOR_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "a ring sector exceeds FEAT_SEG_CAP points (Horizon_SCAN too large for the LDS-resident sector kernel)");
     if (st & DEV_ERR_SECTOR_HANDOVER) return fail(LVI_ERR_HIP, "sector kernel: a workgroup never received its predecessor's hand-over word");
     if (st & DEV_ERR_GRID_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "local map extent too large for the KNN grid");
@@ -168,6 +171,7 @@ void lvi_lidar_params_default(lvi_lidar_params* p)
     p->icp_max_iters = 20; p->icp_disable_break = 0;
     p->max_raw_points = 131072; p->max_map_points = 1 << 20; p->voxel_mode = 0;
     p->max_keyframes = 1024; p->max_keyframe_points = 1 << 22; p->map_on_main_stream = 0;
+    p->sector_handover_wait_us = 0; p->batch_scans = 1;
 }
 
 int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** out)
@@ -384,8 +388,11 @@ int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, 
         if (d.prof.on || d.dk_on) {
             run_stages();                                         // per-kernel HIP events need eager launches; the deskew table's time origin is a kernel argument
         } else {
-            const bool stale = !d.graphExec || d.graph_n_raw != d.n_raw || d.graph_nc != d.n_map_corner || d.graph_ns != d.n_map_surf ||
-                               d.graph_rebuild != (rebuild_map ? 1 : 0);
+            // everything the captured launch sequence froze: sizes, whether a map index exists (icp_init's argument) and the
+            // realisation AUTO picked for each voxel plan (unknown = sorted on a plan's first batch, binned afterwards)
+            const std::array<int, 8> key = {d.n_raw, d.n_map_corner, d.n_map_surf, rebuild_map ? 1 : 0, (d.have_map || rebuild_map) ? 1 : 0,
+                                            voxel_resolve_mode(d.voxRing), voxel_resolve_mode(d.voxScan), voxel_resolve_mode(d.voxMap)};
+            const bool stale = !d.graphExec || key != d.graph_key;
             if (stale) {
                 if (d.graphExec) { (void)hipGraphExecDestroy(d.graphExec); d.graphExec = nullptr; }
                 hipGraph_t graph = nullptr;
@@ -394,7 +401,7 @@ int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, 
                 LVI_HIP(hipStreamEndCapture(d.ctx.stream, &graph));
                 LVI_HIP(hipGraphInstantiate(&d.graphExec, graph, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(graph);
-                d.graph_n_raw = d.n_raw; d.graph_nc = d.n_map_corner; d.graph_ns = d.n_map_surf; d.graph_rebuild = rebuild_map ? 1 : 0;
+                d.graph_key = key;
             }
             d.have_map = d.have_map || rebuild_map; d.have_org = d.have_feat = d.have_ds = true;
             LVI_HIP(hipGraphLaunch(d.graphExec, d.ctx.stream));
@@ -557,6 +564,11 @@ int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_key
     }
     if (tc > h->d.map_cap || ts > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
     return guarded(h, [&]() -> int32_t { stage_map_assemble(h->d, key_indices, n_keys); return LVI_OK; });
+}
+
+int32_t lvi_map_update(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys)
+{
+    return lvi_map_assemble(h, key_indices, n_keys);
 }
 
 int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)
@@ -751,15 +763,19 @@ int32_t lvi_debug_knn(lvi_lidar* h, int32_t which, const lvi_pt* queries, int32_
     if (!h->d.have_map) return fail(LVI_ERR_STATE, "map not built");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
-        lvi_pt* dq = nullptr; int* di = nullptr; float* dd = nullptr;
-        LVI_HIP(hipMalloc((void**)&dq, sizeof(lvi_pt) * std::max(nq, 1)));
-        LVI_HIP(hipMalloc((void**)&di, sizeof(int) * 5 * std::max(nq, 1)));
-        LVI_HIP(hipMalloc((void**)&dd, sizeof(float) * 5 * std::max(nq, 1)));
+        struct Scratch {                                   // freed on every way out, a throwing LVI_HIP included
+            void* p[3] = {nullptr, nullptr, nullptr};
+            ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
+        } sc;
+        const size_t m = (size_t)std::max(nq, 1);
+        LVI_HIP(hipMalloc(&sc.p[0], sizeof(lvi_pt) * m));
+        LVI_HIP(hipMalloc(&sc.p[1], sizeof(int) * 5 * m));
+        LVI_HIP(hipMalloc(&sc.p[2], sizeof(float) * 5 * m));
+        lvi_pt* dq = (lvi_pt*)sc.p[0]; int* di = (int*)sc.p[1]; float* dd = (float*)sc.p[2];
         h2d(d, dq, queries, (size_t)nq);
         debug_knn(d, which, dq, nq, di, dd);
         d2h(d, idx, di, (size_t)nq * 5); d2h(d, sqd, dd, (size_t)nq * 5);
         sync(d);
-        (void)hipFree(dq); (void)hipFree(di); (void)hipFree(dd);
         return check_dev_status(d);
     });
 }

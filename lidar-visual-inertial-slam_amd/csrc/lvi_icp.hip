@@ -41,15 +41,15 @@ struct GridArgs {
     int* d_status;
 };
 
-__global__ void grid_meta_kernel(GridArgs a)
+// d_status[1] is the status word of the map build: every build rewrites it (the scan-side word d_status[0] is cleared by
+// the scan upload, which may come before or after the build on the stream)
+__device__ int grid_meta_one(const GridArgs& a, int w)
 {
-    const int w = threadIdx.x;
-    if (w >= 2) return;
     GridIndex::Meta& m = *a.meta[w];
     const int n = a.nout[w];
     m.n = n; m.ok = 0;
     m.dim[0] = m.dim[1] = m.dim[2] = 1; m.ncells = 1; m.origin[0] = m.origin[1] = m.origin[2] = 0.0;
-    if (n <= 0 || a.vox[w].n_valid == 0) return;
+    if (n <= 0 || a.vox[w].n_valid == 0) return 0;
     double lo[3], ext[3];
     for (int d = 0; d < 3; d++) {
         const double mn = floor((double)ord2f(a.vox[w].bb[d])), mx = floor((double)ord2f(a.vox[w].bb[3 + d]));
@@ -61,13 +61,22 @@ __global__ void grid_meta_kernel(GridArgs a)
         const double e = 0.5 * c;
         const double nx = ceil(ext[0] / e), ny = ceil(ext[1] / e), nz = ceil(ext[2] / e);
         if (nx * ny * nz <= (double)a.max_cells) { m.dim[0] = (int)nx; m.dim[1] = (int)ny; m.dim[2] = (int)nz; break; }
-        if (c > 1 << 20) { atomicOr(a.d_status, DEV_ERR_GRID_TOO_LARGE); return; }
+        if (c > 1 << 20) return DEV_ERR_GRID_TOO_LARGE;
     }
     // cell = floor((p - lo) / edge); a neighbour within 1 m is at most R cells away on every axis
     m.origin[0] = lo[0]; m.origin[1] = lo[1]; m.origin[2] = lo[2];
     m.ncells = m.dim[0] * m.dim[1] * m.dim[2];
     m.edge = 0.5 * c; m.inv_edge = 1.0 / m.edge; m.R = c == 1 ? 2 : 1;
     m.ok = 1;
+    return 0;
+}
+
+__global__ void grid_meta_kernel(GridArgs a)
+{
+    __shared__ int err[2];
+    if (threadIdx.x < 2) err[threadIdx.x] = grid_meta_one(a, threadIdx.x);
+    __syncthreads();
+    if (threadIdx.x == 0) a.d_status[1] = err[0] | err[1];
 }
 
 __device__ __forceinline__ void cell_of(const GridIndex::Meta& m, float x, float y, float z, int c[3])
@@ -424,6 +433,7 @@ struct IcpArgs {
     int imu_available; float imu_roll, imu_pitch;
     void* d_record;
     long long* cyc;
+    const int* d_status;                          // [2] device error words: scan side, map build
 };
 
 __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
@@ -877,6 +887,10 @@ __device__ void icp_finish_body(const IcpArgs& a)
         T[5] = fminf(fmaxf(T[5], -a.z_tol), a.z_tol);
         if (!s.any_lm) s.status = LVI_TOO_FEW_CORRESPONDENCES;
     }
+    // a device-side error of the stages that fed this scan match (sector capacity, KNN grid size) travels in the record:
+    // the async / replay entry points have no other channel back to the caller
+    const int dev = a.d_status[0] | a.d_status[1];
+    if (dev) s.status = (dev & DEV_ERR_SECTOR_HANDOVER) ? LVI_ERR_HIP : LVI_ERR_CAPACITY;
     for (int k = 0; k < 6; k++) { s.final_pose[k] = T[k]; s.record.pose[k] = T[k]; }
     s.record.status = s.status; s.record.iters = s.iters;
     if (a.d_record) *reinterpret_cast<lvi_pose_record*>(a.d_record) = s.record;
@@ -937,7 +951,7 @@ IcpArgs icp_args(LidarDev& d)
     a.q[0] = d.cornerDS; a.q[1] = d.surfDS; a.nq = d.voxScan.d_nout;
     for (int w = 0; w < 2; w++) { a.meta[w] = d.grid[w].meta; a.cell_start[w] = d.grid[w].cell_start; a.sorted[w] = d.grid[w].sorted; }
     a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
-    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles;
+    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles; a.d_status = d.d_status;
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;

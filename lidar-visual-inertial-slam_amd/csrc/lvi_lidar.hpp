@@ -78,6 +78,7 @@ struct LidarDev {
     // ---- a-1..a-3
     float* curv = nullptr; uint8_t *picked = nullptr, *picked_occl = nullptr, *surfmask = nullptr, *pflags = nullptr; int8_t* label = nullptr;
     unsigned* sectorSpill = nullptr;                       // [MAX_N_SCAN * 6][2] hand-over words of the pipelined sector kernel
+    long long feat_handover_ticks = 200000;                // 2 ms at 100 MHz: wait of a pipelined sector workgroup before it redoes the ring itself (LVI_FEAT_HANDOVER_TICKS)
     int *sector_idx = nullptr, *sector_cnt = nullptr;      // [N_SCAN*6*40], [N_SCAN*6]
     lvi_pt* corner = nullptr; int* corner_idx = nullptr; int* d_ncorner = nullptr;
     lvi_pt* surf = nullptr;                                // concatenated per-ring DS output
@@ -108,7 +109,7 @@ struct LidarDev {
     float* d_pose_init = nullptr;                          // [6] initial guess of the next scan match (device)
     // captured launch sequence of the whole per-scan path (lvi_scan_replay_enqueue)
     hipGraphExec_t graphExec = nullptr;
-    int graph_n_raw = -1, graph_nc = -1, graph_ns = -1, graph_rebuild = -1;
+    std::array<int, 8> graph_key = {-1, -1, -1, -1, -1, -1, -1, -1};   // what the capture froze (lvi_scan_replay_enqueue)
     // stage flags (host)
     bool have_raw = false, have_org = false, have_feat = false, have_ds = false, have_map_raw = false, have_map = false;
     bool gen_valid = false; int gen_n = 0;

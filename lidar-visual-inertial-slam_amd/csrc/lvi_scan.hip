@@ -249,6 +249,7 @@ struct FeatArgs {
     int* d_fresh; int* d_status; long long* cyc;
     VoxSegDyn* ringDyn; VoxSegDyn* scanDyn; const int* ringNout;
     int N_SCAN; float edgeThreshold, surfThreshold;
+    long long handover_ticks;   // wall_clock64 ticks (100 MHz) a pipelined sector workgroup waits for its predecessor before it redoes the ring itself
 };
 
 __device__ __forceinline__ bool occl_A(const float* r, const int* col, int i)     // depth1 - depth2 > 0.3 at loop index i
@@ -329,16 +330,18 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
     __shared__ unsigned long long s_key[FEAT_SEG_CAP];        // corner candidates: (curvature bits << 32) | local index
     __shared__ unsigned short s_sorted[FEAT_SEG_CAP];         // candidates by descending key
     __shared__ int s_ws[FEAT_THREADS / 64 + 2];
-    __shared__ int s_any;
+    __shared__ int s_any, s_timeout;
 
     // One workgroup per (ring, sector) when every sector of the ring is a regular one; the six workgroups of a ring
     // form a pipeline: loading, neighbour reach, candidate compaction and ranking of sector s+1 run while sector s is
     // in its greedy walks; what s+1 needs from s — the marks on its first five points — arrives in ONE device-scope
     // atomic word (5 flag bits + a ready bit), so no memory fence (= L2 write-back on this multi-XCD part) is involved.
-    // Workgroups are dispatched in blockIdx order, a producer always before its consumer, and a ring needs 6 of the
-    // 256 CUs, so a waiting consumer can never keep its producer from running (as long as all such workgroups in
-    // flight fit the chip: hence the 4-ring limit below; a bounded spin turns a lost hand-over into an error).  Rings with a degenerate sector
-    // (< 66 points) take the sequential form: the sector-0 workgroup walks all six (carry through LDS, as before).
+    // HIP does not promise that a producer workgroup is resident before its consumer (several such launches in flight
+    // from different streams can fill every CU with waiting consumers), so no workgroup DEPENDS on another one: a consumer
+    // waits a bounded wall-clock time (FEAT_HANDOVER_TICKS) for the word and then walks the ring from sector 0 itself
+    // ("redo": the same deterministic computation its predecessors do, carry through LDS, identical values written),
+    // which always terminates.  Rings with a degenerate sector (< 66 points) take the sequential form from the start:
+    // the sector-0 workgroup walks all six.
     const int ring = blockIdx.x / 6, my_sec = blockIdx.x % 6;
     const int n = *a.d_n;
     const int tid = threadIdx.x;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
 #define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
 
     if (tid < 4) { s_U[tid == 0 ? 0 : FEAT_THREADS + tid] = 0; s_L[tid == 0 ? 0 : FEAT_THREADS + tid] = 0; }
-    if (tid == 0) s_brk[FEAT_SEG_CAP / 64] = ~0ull, s_brk[FEAT_SEG_CAP / 64 + 1] = ~0ull;
+    if (tid == 0) { s_brk[FEAT_SEG_CAP / 64] = ~0ull, s_brk[FEAT_SEG_CAP / 64 + 1] = ~0ull; s_timeout = 0; }
     for (int j = FEAT_SEG_CAP + tid; j < FEAT_SEG_CAP + 32; j += FEAT_THREADS) s_curv[j] = 0.f;
     __syncthreads();
 
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
     const int sec_begin = piped ? my_sec : 0, sec_end = piped ? my_sec + 1 : 6;
     prefetch(sec_begin);
     int carry_k = -1; uint8_t carry_v = 0;            // threads 0..9: picked flags of global points carry_k .. carry_k + 9 as the last sector left them
+    bool redo = false;                                // pipelined workgroup that gave up waiting: walks sectors 0 .. my_sec itself
 
     for (int sec = sec_begin; sec < sec_end; sec++) {
         int sp, ep;
@@ -486,19 +490,28 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
         }
         __syncthreads();
         LVI_STAMP(2);
-        if (piped && sec > 0) {
+        if (piped && sec > 0 && !redo) {
             // hand-over from sector sec-1: marks on this sector's first five points (local 5..9)
             if (tid == 0) {
                 unsigned v = 0u;
-                long long spins = 0;
+                const long long t_give_up = wall_clock64() + a.handover_ticks;
                 while (!((v = atomicOr(&a.spill[(ring * 6 + sec - 1) * 2], 0u)) & 0x80000000u)) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (++spins > (1ll << 26)) { atomicOr(a.d_status, DEV_ERR_SECTOR_HANDOVER); break; }     // minutes: a lost producer, not contention
+                    if (wall_clock64() > t_give_up) { s_timeout = 1; break; }
                 }
 #pragma unroll
                 for (int i = 0; i < 5; i++) if ((v >> i) & 1u) s_pick[5 + i] = 1;
             }
             __syncthreads();
+            if (s_timeout) {
+                // the producer is not making progress (or not resident): do its work here.  Every value written on the way is
+                // the one the owner writes (same inputs, same deterministic walk), write-back keeps the pipelined rule.
+                redo = true; carry_k = -1;
+                prefetch(0);
+                sec = -1;
+                __syncthreads();
+                continue;
+            }
         }
         if (tid < 64) {
             const int l = tid;
@@ -634,7 +647,6 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
     }
     if (stamp) for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q];
 #undef LVI_STAMP
-    if (blockIdx.x == 0 && tid == 0 && n > 16) *a.d_fresh = 0;
 }
 
 // corners in output order (ring, sector, pick order) + segment descriptors of the per-ring VoxelGrid
@@ -648,6 +660,7 @@ __global__ void feat_finalize_kernel(FeatArgs a)
         off[ns] = o;
         *a.d_ncorner = o;
         for (int r = 0; r < a.N_SCAN; r++) { a.ringDyn[r].in_off = a.ringBase[r]; a.ringDyn[r].n = a.ringBase[r + 1] - a.ringBase[r]; }
+        if (*a.d_n > 16) *a.d_fresh = 0;              // the "fresh node" case ends with the first real scan
     }
     __syncthreads();
     // pipelined sector kernel: marks a sector made on the last five points of its predecessor
@@ -688,7 +701,7 @@ void layout(AR& ar, LidarDev& d)
     d.corner = ar.template alloc<lvi_pt>(d.ext_cap); d.corner_idx = ar.template alloc<int>((size_t)NS * 6 * CORNERS_PER_SECTOR);
     d.d_ncorner = ar.template alloc<int>(1);
     d.surf = ar.template alloc<lvi_pt>(d.ext_cap);
-    d.d_fresh = ar.template alloc<int>(1); d.d_status = ar.template alloc<int>(1); d.d_feat_cycles = ar.template alloc<long long>(8); d.d_icp_cycles = ar.template alloc<long long>(16);
+    d.d_fresh = ar.template alloc<int>(1); d.d_status = ar.template alloc<int>(2); d.d_feat_cycles = ar.template alloc<long long>(8); d.d_icp_cycles = ar.template alloc<long long>(16);
     d.voxRing.allocate(ar, NS, d.ring_cap, true);
     d.cornerDS = ar.template alloc<lvi_pt>(d.ext_cap); d.surfDS = ar.template alloc<lvi_pt>(d.ext_cap);
     d.voxScan.allocate(ar, 2, d.ext_cap, false);
@@ -727,6 +740,7 @@ FeatArgs feat_args(LidarDev& d)
     a.d_fresh = d.d_fresh; a.d_status = d.d_status; a.cyc = d.d_feat_cycles;
     a.ringDyn = d.voxRing.d_dyn; a.scanDyn = d.voxScan.d_dyn; a.ringNout = d.voxRing.d_nout;
     a.N_SCAN = d.P.N_SCAN; a.edgeThreshold = d.P.edgeThreshold; a.surfThreshold = d.P.surfThreshold;
+    a.handover_ticks = d.feat_handover_ticks;
     return a;
 }
 
@@ -742,7 +756,10 @@ void lidar_allocate(LidarDev& d)
     d.nblk_org = div_up(d.raw_cap, ORG_TILE);
     d.kf_pool_cap = d.P.max_keyframes > 0 ? std::max(d.P.max_keyframe_points, 0) : 0;
     d.kf_seg_cap = 2 * std::max(d.P.max_keyframes, 0) + 2048;       // an assembly may list a key more than once
-    d.max_cells = 1 << 24;
+    // cells of the KNN grid (0.5 m, or the next multiple that fits): sized from the map capacity — three int arrays per grid
+    // and map, 400 MB at 2^24 — so that small handles stay small; a map whose extent needs more gets coarser cells (still exact)
+    d.max_cells = (int)std::min<long long>(1ll << 24, std::max<long long>(1ll << 18, 4ll * d.map_cap));
+    d.feat_handover_ticks = d.P.sector_handover_wait_us < 0 ? 0 : 100ll * (d.P.sector_handover_wait_us > 0 ? d.P.sector_handover_wait_us : 2000);
     d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / KNN_G);
     ArenaSizer sz;
     layout(sz, d);

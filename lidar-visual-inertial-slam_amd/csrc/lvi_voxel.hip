@@ -811,19 +811,23 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
     LVI_HIP(hipStreamSynchronize(ctx.stream));
 }
 
+int voxel_resolve_mode(const VoxelPlan& p)
+{
+    if (p.mode != VOX_AUTO) return p.mode;
+    // hint of the previous batch of this plan (pinned host memory written by vox_setup; a racing read returns the
+    // older or the newer value, and either path is correct for any grid)
+    int mode = VOX_BINNED;
+    for (int s = 0; s < p.nseg; s++)
+        // up to four 1024-voxel sub-ranges per bin the binned path still wins (4 M sparse points, 12.5 M cells: 341 vs
+        // 416 us); at 100 M cells it is 4x slower than the sort (tools/ubench/sparse_voxel.py)
+        if (!p.h_ncells || p.h_ncells[s] > ((unsigned long long)VB_NB << (VB_CL_LOG + 2))) mode = VOX_SORTED;
+    return mode;
+}
+
 void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
 {
     const VoxArgs a = make_args(p);
-    int mode = p.mode;
-    if (mode == VOX_AUTO) {
-        // hint of the previous batch of this plan (pinned host memory written by vox_setup; a racing read returns the
-        // older or the newer value, and either path is correct for any grid)
-        mode = VOX_BINNED;
-        for (int s = 0; s < p.nseg; s++)
-            // up to four 1024-voxel sub-ranges per bin the binned path still wins (4 M sparse points, 12.5 M cells: 341 vs
-            // 416 us); at 100 M cells it is 4x slower than the sort (tools/ubench/sparse_voxel.py)
-            if (!p.h_ncells || p.h_ncells[s] > ((unsigned long long)VB_NB << (VB_CL_LOG + 2))) mode = VOX_SORTED;
-    }
+    const int mode = voxel_resolve_mode(p);
     p.last_mode = mode;
     char nm[16][48];
     const char* base[16] = {"vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid",

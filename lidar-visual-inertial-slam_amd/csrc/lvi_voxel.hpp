@@ -127,5 +127,7 @@ struct VoxelPlan {
 // 16.8 M cells (four sweeps per bin), SORTED for sparser ones.  d_dyn must have been written (on the same
 // stream) by the producer.  n_hint: nominal total input points, for byte accounting only.
 void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& plan, const char* tag, double n_hint);
+// the realisation the next voxel_downsample_batch of this plan will enqueue (AUTO resolved from the previous batch's hint)
+int voxel_resolve_mode(const VoxelPlan& plan);
 
 }  // namespace lvi

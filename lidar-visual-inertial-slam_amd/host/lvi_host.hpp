@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -178,6 +180,229 @@ private:
     bool haveMap_ = false;
 };
 
+// ---------------------------------------------------------------------------------------------- mapOptimization (caller loop)
+// The part of mapOptimization around scan matching that decides WHICH keyframes form the local map and WHEN a scan
+// becomes a keyframe: updateInitialGuess (:806-877), extractNearby (:894-929), extractCloud's
+// key selection (:931-957), saveFrame (:1387-1412), the key-pose push of saveKeyFramesAndFactor (:1575-1599).
+// Key POSES are a few thousand points: host work.  Key CLOUDS never leave the device (lvi_keyframe_*, lvi_map_*).
+// iSAM2 / loop closure / GPS are out of scope: with only the prior and odometry factors the newest
+// estimate of iSAM2 is the scan-matching result, which is what is pushed here ("odometry chain").
+struct Affine3f { float m[3][4]; };            // Eigen::Affine3f: linear part | translation
+inline Affine3f getTransformation(float x, float y, float z, float roll, float pitch, float yaw)      // pcl::getTransformation
+{
+    const float A = std::cos(yaw), B = std::sin(yaw), C = std::cos(pitch), D = std::sin(pitch), E = std::cos(roll), F = std::sin(roll), DE = D * E, DF = D * F;
+    return Affine3f{{{A * C, A * DF - B * E, B * F + A * DE, x}, {B * C, A * E + B * DF, B * DE - A * F, y}, {-D, C * F, C * E, z}}};
+}
+inline Affine3f affineInverse(const Affine3f& t)                      // Eigen Transform::inverse(Affine): cofactor inverse of the 3x3, -inv * translation
+{
+    const float (*R)[4] = t.m;
+    auto cof = [&](int i, int j) { return R[(i + 1) % 3][(j + 1) % 3] * R[(i + 2) % 3][(j + 2) % 3] - R[(i + 1) % 3][(j + 2) % 3] * R[(i + 2) % 3][(j + 1) % 3]; };
+    const float c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+    const float invdet = 1.0f / ((c0 * R[0][0] + c1 * R[1][0]) + c2 * R[2][0]);
+    Affine3f o;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o.m[i][j] = cof(j, i) * invdet;
+    for (int i = 0; i < 3; i++) o.m[i][3] = -((o.m[i][0] * R[0][3] + o.m[i][1] * R[1][3]) + o.m[i][2] * R[2][3]);
+    return o;
+}
+inline Affine3f affineMul(const Affine3f& a, const Affine3f& b)
+{
+    Affine3f o;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) o.m[i][j] = (a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j];
+        o.m[i][3] = ((a.m[i][0] * b.m[0][3] + a.m[i][1] * b.m[1][3]) + a.m[i][2] * b.m[2][3]) + a.m[i][3];
+    }
+    return o;
+}
+inline void getTranslationAndEulerAngles(const Affine3f& t, float& x, float& y, float& z, float& roll, float& pitch, float& yaw)   // pcl (App. A.3)
+{
+    x = t.m[0][3]; y = t.m[1][3]; z = t.m[2][3];
+    roll = std::atan2(t.m[2][1], t.m[2][2]); pitch = std::asin(-t.m[2][0]); yaw = std::atan2(t.m[1][0], t.m[0][0]);
+}
+
+struct PointTypePose { float x, y, z, intensity, roll, pitch, yaw; double time; };     // utility.h:71-78
+
+struct MapCallerParams {                       // params_lidar.yaml:17,60-66 (utility.h:176,278-288)
+    bool   useImuHeadingInitialization = false;
+    double mappingProcessInterval = 0.15;
+    float  surroundingkeyframeAddingDistThreshold = 1.0f;
+    float  surroundingkeyframeAddingAngleThreshold = 0.2f;
+    float  surroundingKeyframeDensity = 2.0f;
+    float  surroundingKeyframeSearchRadius = 50.0f;
+    bool   sensorIsLivox = true;               // sensor == SensorType::LIVOX (:1392-1396)
+    bool   incrementalMap = true;              // lvi_map_update (keyframes entering / leaving the local map) instead of lvi_map_assemble; same bits
+};
+
+class MapOptimizationNode {
+public:
+    MapOptimizationNode(LidarHandle& h, const MapCallerParams& p = MapCallerParams()) : P(p), h_(h) { for (float& v : transformTobeMapped) v = 0.f; }
+    MapCallerParams P;
+    float transformTobeMapped[6];
+    std::vector<lvi_pt> cloudKeyPoses3D;       // x, y, z, intensity = index
+    std::vector<PointTypePose> cloudKeyPoses6D;
+    std::vector<int32_t> lastKeys;             // key indices of the last extractCloud, in fuse order
+    lvi_icp_result last{};
+    int32_t lastStatus = LVI_NO_MAP;
+    bool lastSavedKeyFrame = false, lastProcessed = false;
+
+    // laserCloudInfoHandler (:298-333) with the feature clouds of the message.  Returns false when the
+    // mappingProcessInterval gate dropped the scan.
+    bool laserCloudInfoHandler(const CloudInfo& cloudInfo)
+    {
+        timeLaserInfoCur = cloudInfo.stamp;
+        lastProcessed = false;
+        if (!(timeLaserInfoCur - timeLastProcessing >= P.mappingProcessInterval)) return false;
+        timeLastProcessing = timeLaserInfoCur;
+        lastProcessed = true;
+        updateInitialGuess(cloudInfo);
+        extractSurroundingKeyFrames();
+        // downsampleCurrentScan + scan2MapOptimization (:987-999, 1315-1343): one C-ABI call; without key poses it only downsamples
+        lvi_imu_hint imu{(int32_t)cloudInfo.imu_available, cloudInfo.imu_roll_init, cloudInfo.imu_pitch_init, cloudInfo.imu_yaw_init};
+        lastStatus = check(lvi_scan_to_map(h_.get(), cloudInfo.cloud_corner.data(), (int32_t)cloudInfo.cloud_corner.size(),
+                                           cloudInfo.cloud_surface.data(), (int32_t)cloudInfo.cloud_surface.size(), &imu, transformTobeMapped, &last),
+                           "lvi_scan_to_map");
+        saveKeyFramesAndFactor();
+        return true;
+    }
+    // the same for a scan whose features already sit on the device (replay harness: lvi_scan_upload* / organize / extract ran)
+    bool processResidentScan(double stamp, const lvi_imu_hint& imu)
+    {
+        CloudInfo ci; ci.stamp = stamp; ci.imu_available = imu.imu_available;
+        ci.imu_roll_init = imu.imu_roll_init; ci.imu_pitch_init = imu.imu_pitch_init; ci.imu_yaw_init = imu.imu_yaw_init;
+        timeLaserInfoCur = stamp;
+        lastProcessed = false;
+        if (!(timeLaserInfoCur - timeLastProcessing >= P.mappingProcessInterval)) return false;
+        timeLastProcessing = timeLaserInfoCur;
+        lastProcessed = true;
+        updateInitialGuess(ci);
+        extractSurroundingKeyFrames();
+        check(lvi_scan_downsample(h_.get()), "lvi_scan_downsample");
+        lastStatus = check(lvi_scan_match(h_.get(), &imu, transformTobeMapped, &last), "lvi_scan_match");
+        saveKeyFramesAndFactor();
+        return true;
+    }
+
+    void updateInitialGuess(const CloudInfo& cloudInfo)                                   // :806-877
+    {
+        if (cloudKeyPoses3D.empty()) {
+            transformTobeMapped[0] = cloudInfo.imu_roll_init; transformTobeMapped[1] = cloudInfo.imu_pitch_init; transformTobeMapped[2] = cloudInfo.imu_yaw_init;
+            if (!P.useImuHeadingInitialization) transformTobeMapped[2] = 0;
+            lastImuTransformation = getTransformation(0, 0, 0, cloudInfo.imu_roll_init, cloudInfo.imu_pitch_init, cloudInfo.imu_yaw_init);
+            return;
+        }
+        if (cloudInfo.odom_available && cloudInfo.odom_reset_id == odom_reset_id) {       // VINS odometry guess (:825-851)
+            const Affine3f transBack = getTransformation(cloudInfo.initial_guess_x, cloudInfo.initial_guess_y, cloudInfo.initial_guess_z,
+                                                         cloudInfo.initial_guess_roll, cloudInfo.initial_guess_pitch, cloudInfo.initial_guess_yaw);
+            if (!lastVinsTransAvailable) {
+                lastVinsTransformation = transBack; lastVinsTransAvailable = true;
+            } else {
+                applyIncrement(affineMul(affineInverse(lastVinsTransformation), transBack));
+                lastVinsTransformation = transBack;
+                lastImuTransformation = getTransformation(0, 0, 0, cloudInfo.imu_roll_init, cloudInfo.imu_pitch_init, cloudInfo.imu_yaw_init);
+                return;
+            }
+        } else {
+            lastVinsTransAvailable = false; odom_reset_id = cloudInfo.odom_reset_id;
+        }
+        if (cloudInfo.imu_available) {                                                    // IMU rotation increment (:859-871)
+            const Affine3f transBack = getTransformation(0, 0, 0, cloudInfo.imu_roll_init, cloudInfo.imu_pitch_init, cloudInfo.imu_yaw_init);
+            applyIncrement(affineMul(affineInverse(lastImuTransformation), transBack));
+            lastImuTransformation = transBack;
+        }
+    }
+
+    void extractSurroundingKeyFrames() { if (!cloudKeyPoses3D.empty()) extractNearby(); }   // :968-981
+
+    void extractNearby()                                                                  // :894-929
+    {
+        const lvi_pt back = cloudKeyPoses3D.back();
+        const double radius = (double)P.surroundingKeyframeSearchRadius;
+        // kdtree radiusSearch (sorted by distance; brute force over the key poses, ties by index)
+        std::vector<std::pair<float, int>> hits;
+        for (int i = 0; i < (int)cloudKeyPoses3D.size(); i++) {
+            const float d = sqDist(cloudKeyPoses3D[i], back);
+            if ((double)d <= radius * radius) hits.push_back({d, i});
+        }
+        std::stable_sort(hits.begin(), hits.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        std::vector<lvi_pt> surroundingKeyPoses;
+        for (auto& hpair : hits) surroundingKeyPoses.push_back(cloudKeyPoses3D[hpair.second]);
+        // downSizeFilterSurroundingKeyPoses: the library's VoxelGrid, leaf surroundingKeyframeDensity
+        std::vector<lvi_pt> surroundingKeyPosesDS(std::max<size_t>(surroundingKeyPoses.size(), 1));
+        int32_t nds = 0;
+        check(lvi_voxel_downsample(h_.get(), surroundingKeyPoses.data(), (int32_t)surroundingKeyPoses.size(), P.surroundingKeyframeDensity,
+                                   surroundingKeyPosesDS.data(), (int32_t)surroundingKeyPosesDS.size(), &nds), "lvi_voxel_downsample(key poses)");
+        surroundingKeyPosesDS.resize(nds);
+        for (auto& pt : surroundingKeyPosesDS) {                                          // nearestKSearch(pt, 1) → the key's index
+            int best = 0; float bd = sqDist(cloudKeyPoses3D[0], pt);
+            for (int i = 1; i < (int)cloudKeyPoses3D.size(); i++) { const float d = sqDist(cloudKeyPoses3D[i], pt); if (d < bd) { bd = d; best = i; } }
+            pt.intensity = cloudKeyPoses3D[best].intensity;
+        }
+        for (int i = (int)cloudKeyPoses3D.size() - 1; i >= 0; --i) {                      // the latest key frames (robot rotating in place)
+            if (timeLaserInfoCur - cloudKeyPoses6D[i].time < 10.0) surroundingKeyPosesDS.push_back(cloudKeyPoses3D[i]);
+            else break;
+        }
+        extractCloud(surroundingKeyPosesDS);
+    }
+
+    void extractCloud(const std::vector<lvi_pt>& cloudToExtract)                          // :931-965
+    {
+        lastKeys.clear();
+        for (const lvi_pt& pt : cloudToExtract) {
+            if (std::sqrt(sqDist(pt, cloudKeyPoses3D.back())) > P.surroundingKeyframeSearchRadius) continue;     // pointDistance (utility.h:408-411)
+            lastKeys.push_back((int32_t)pt.intensity);
+        }
+        if (P.incrementalMap) check(lvi_map_update(h_.get(), lastKeys.data(), (int32_t)lastKeys.size()), "lvi_map_update");
+        else check(lvi_map_assemble(h_.get(), lastKeys.data(), (int32_t)lastKeys.size()), "lvi_map_assemble");
+    }
+
+    bool saveFrame() const                                                                // :1387-1412
+    {
+        if (cloudKeyPoses3D.empty()) return true;
+        if (P.sensorIsLivox && timeLaserInfoCur - cloudKeyPoses6D.back().time > 1.0) return true;
+        const PointTypePose& b = cloudKeyPoses6D.back();
+        const Affine3f transStart = getTransformation(b.x, b.y, b.z, b.roll, b.pitch, b.yaw);      // pclPointToAffine3f
+        const Affine3f transFinal = getTransformation(transformTobeMapped[3], transformTobeMapped[4], transformTobeMapped[5],
+                                                      transformTobeMapped[0], transformTobeMapped[1], transformTobeMapped[2]);
+        float x, y, z, roll, pitch, yaw;
+        getTranslationAndEulerAngles(affineMul(affineInverse(transStart), transFinal), x, y, z, roll, pitch, yaw);
+        if (std::abs(roll) < P.surroundingkeyframeAddingAngleThreshold && std::abs(pitch) < P.surroundingkeyframeAddingAngleThreshold &&
+            std::abs(yaw) < P.surroundingkeyframeAddingAngleThreshold && std::sqrt(x * x + y * y + z * z) < P.surroundingkeyframeAddingDistThreshold)
+            return false;
+        return true;
+    }
+
+    void saveKeyFramesAndFactor()                                                         // :1529-1603 without the factor graph
+    {
+        lastSavedKeyFrame = false;
+        if (!saveFrame()) return;
+        lvi_pt thisPose3D{transformTobeMapped[3], transformTobeMapped[4], transformTobeMapped[5], (float)cloudKeyPoses3D.size()};
+        PointTypePose thisPose6D{thisPose3D.x, thisPose3D.y, thisPose3D.z, thisPose3D.intensity,
+                                 transformTobeMapped[0], transformTobeMapped[1], transformTobeMapped[2], timeLaserInfoCur};
+        int32_t idx = -1;                                                                 // cornerCloudKeyFrames / surfCloudKeyFrames push_back: device to device
+        check(lvi_keyframe_add_current(h_.get(), transformTobeMapped, &idx), "lvi_keyframe_add_current");
+        if (idx != (int32_t)cloudKeyPoses3D.size()) throw Error(LVI_ERR_STATE, "keyframe store out of step with the key poses");
+        cloudKeyPoses3D.push_back(thisPose3D); cloudKeyPoses6D.push_back(thisPose6D);
+        lastSavedKeyFrame = true;
+    }
+private:
+    static float sqDist(const lvi_pt& a, const lvi_pt& b)
+    {
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+        return (dx * dx + dy * dy) + dz * dz;
+    }
+    void applyIncrement(const Affine3f& transIncre)
+    {
+        const Affine3f transTobe = getTransformation(transformTobeMapped[3], transformTobeMapped[4], transformTobeMapped[5],
+                                                     transformTobeMapped[0], transformTobeMapped[1], transformTobeMapped[2]);      // trans2Affine3f
+        getTranslationAndEulerAngles(affineMul(transTobe, transIncre), transformTobeMapped[3], transformTobeMapped[4], transformTobeMapped[5],
+                                     transformTobeMapped[0], transformTobeMapped[1], transformTobeMapped[2]);
+    }
+    LidarHandle& h_;
+    double timeLaserInfoCur = 0.0, timeLastProcessing = -1.0;
+    Affine3f lastImuTransformation{}, lastVinsTransformation{};
+    bool lastVinsTransAvailable = false;
+    int64_t odom_reset_id = 0;
+};
+
 // ---------------------------------------------------------------------------------------------- FeatureTracker
 struct Point2f { float x, y; };
 
@@ -268,8 +493,58 @@ public:
     std::map<int, Point2f> cur_un_pts_map, prev_un_pts_map;
     double cur_time = 0.0, prev_time = 0.0;
 
-    // readImage without rejectWithF (findFundamentalMat RANSAC stays on the host).  `img` is ROW x COL,
-    // 8-bit, tightly packed.
+    // cv::findFundamentalMat(un_cur_pts, un_forw_pts, cv::FM_RANSAC, F_THRESHOLD, 0.99, status) of rejectWithF
+    // (feature_tracker.cpp:209-242).  The RANSAC itself is host-side OpenCV in the reference and stays with the node
+    // (not a kernel); the node installs it here.  Without a hook — or without a camera — readImage
+    // skips the call and says so in rejectWithF_skipped, so a caller comparing against the reference knows that the
+    // point set entering setMask may be larger than the reference's.
+    using FundamentalMatFn = std::function<void(const std::vector<Point2f>& un_cur_pts, const std::vector<Point2f>& un_forw_pts,
+                                                double F_THRESHOLD, std::vector<uint8_t>& status)>;
+    FundamentalMatFn findFundamentalMat;
+    double F_THRESHOLD = 1.0;                                   // params_camera.yaml F_threshold
+    int FOCAL_LENGTH = 460;                                     // parameters.cpp:101
+    int rejectWithF_skipped = 0;                                // PUB frames on which >= 8 points were tracked but no hook was installed
+
+    // CataCamera::liftProjective (CataCamera.cc:556-626, distortion :766-783) in double on the host: rejectWithF needs the
+    // double ray before it is scaled by FOCAL_LENGTH (the device version, lvi_undistort_points, returns f32 x/z, y/z)
+    void liftProjective(double px, double py, double P[3]) const
+    {
+        const double inv_K11 = 1.0 / cam_.gamma1, inv_K13 = -cam_.u0 / cam_.gamma1, inv_K22 = 1.0 / cam_.gamma2, inv_K23 = -cam_.v0 / cam_.gamma2;
+        const double mx_d = inv_K11 * px + inv_K13, my_d = inv_K22 * py + inv_K23;
+        auto distortion = [&](double ux, double uy, double& dx, double& dy) {
+            const double mx2_u = ux * ux, my2_u = uy * uy, mxy_u = ux * uy, rho2_u = mx2_u + my2_u;
+            const double rad_dist_u = cam_.k1 * rho2_u + cam_.k2 * rho2_u * rho2_u;
+            dx = ux * rad_dist_u + 2.0 * cam_.p1 * mxy_u + cam_.p2 * (rho2_u + 2.0 * mx2_u);
+            dy = uy * rad_dist_u + 2.0 * cam_.p2 * mxy_u + cam_.p1 * (rho2_u + 2.0 * my2_u);
+        };
+        double dx, dy;
+        distortion(mx_d, my_d, dx, dy);
+        double mx_u = mx_d - dx, my_u = my_d - dy;
+        for (int i = 1; i < 8; ++i) { distortion(mx_u, my_u, dx, dy); mx_u = mx_d - dx; my_u = my_d - dy; }
+        const double xi = cam_.xi;
+        P[0] = mx_u; P[1] = my_u;
+        if (xi == 1.0) P[2] = (1.0 - mx_u * mx_u - my_u * my_u) / 2.0;
+        else { const double rho2_d = mx_u * mx_u + my_u * my_u; P[2] = 1.0 - xi * (rho2_d + 1.0) / (xi + std::sqrt(1.0 + (1.0 - xi * xi) * rho2_d)); }
+    }
+    void rejectWithF()                                          // feature_tracker.cpp:209-242
+    {
+        if (forw_pts.size() < 8) return;
+        if (!findFundamentalMat || !have_cam_) { rejectWithF_skipped++; return; }
+        std::vector<Point2f> un_cur_pts(cur_pts.size()), un_forw_pts(forw_pts.size());
+        for (size_t i = 0; i < cur_pts.size(); i++) {
+            double tmp_p[3];
+            liftProjective(cur_pts[i].x, cur_pts[i].y, tmp_p);
+            un_cur_pts[i] = Point2f{(float)(FOCAL_LENGTH * tmp_p[0] / tmp_p[2] + COL / 2.0), (float)(FOCAL_LENGTH * tmp_p[1] / tmp_p[2] + ROW / 2.0)};
+            liftProjective(forw_pts[i].x, forw_pts[i].y, tmp_p);
+            un_forw_pts[i] = Point2f{(float)(FOCAL_LENGTH * tmp_p[0] / tmp_p[2] + COL / 2.0), (float)(FOCAL_LENGTH * tmp_p[1] / tmp_p[2] + ROW / 2.0)};
+        }
+        std::vector<uint8_t> status(cur_pts.size(), 1);
+        findFundamentalMat(un_cur_pts, un_forw_pts, F_THRESHOLD, status);
+        reduceVector(prev_pts, status); reduceVector(cur_pts, status); reduceVector(forw_pts, status);
+        reduceVector(ids, status); reduceVector(track_cnt, status);
+    }
+
+    // readImage (feature_tracker.cpp:81-207).  `img` is ROW x COL, 8-bit, tightly packed.
     void readImage(const uint8_t* img, double _cur_time = 0.0)
     {
         cur_time = _cur_time;
@@ -289,6 +564,7 @@ public:
         }
         for (auto& n : track_cnt) n++;                                                            // :150-151
         if (PUB_THIS_FRAME) {
+            rejectWithF();                                                                        // :153
             setMask();
             const int n_max_cnt = MAX_CNT - (int)forw_pts.size();
             if (n_max_cnt > 0) {
@@ -343,6 +619,82 @@ private:
     TrackerHandle& t_;
     int ROW, COL, MAX_CNT, MIN_DIST;
     lvi_mei_params cam_{}; bool have_cam_ = false;
+};
+
+// ---------------------------------------------------------------------------------------------- feature_tracker_node
+// img_callback (feature_tracker_node.cpp:37-231) for NUM_OF_CAM == 1 without ROS: first-image / discontinuity handling,
+// the frequency control that sets PUB_THIS_FRAME, updateID, and the assembly of the /vins/feature/feature message
+// (sensor_msgs/PointCloud: points = (un_x, un_y, 1); channels = id, u, v, vx, vy, depth; frame_id "vins_body"; only
+// features with track_cnt > 1; the first assembled message is not published).
+struct Point3f { float x, y, z; };
+struct FeatureMsg {
+    double stamp = 0.0;
+    std::string frame_id;
+    std::vector<Point3f> points;
+    std::vector<float> channels[6];             // id_of_point, u, v, velocity_x, velocity_y, depth (in this order, :204-224)
+};
+
+class FeatureTrackerNode {
+public:
+    enum Outcome { FIRST_IMAGE = 0, RESTART = 1, NOT_PUBLISHED = 2, FIRST_PUBLISH_SUPPRESSED = 3, PUBLISHED = 4 };
+    static constexpr int NUM_OF_CAM = 1;
+    FeatureTrackerNode(FeatureTracker& ft, int freq) : trackerData(ft), FREQ(freq == 0 ? 100 : freq) {}   // parameters.cpp:104-105
+
+    // DepthRegister::get_depth (feature_tracker.h:116-): lidar depth association is outside the hot path; the
+    // node may install it.  Default = the reference's own initial value when no depth cloud is available: -1 per feature.
+    std::function<std::vector<float>(double stamp, const std::vector<Point3f>& features_2d)> get_depth;
+    int restarts = 0;                           // /vins/feature/restart messages that would have been published (:56-58)
+
+    Outcome img_callback(const uint8_t* img, double cur_img_time, FeatureMsg* feature_points)
+    {
+        if (first_image_flag) {                                                            // :41-47
+            first_image_flag = false; first_image_time = cur_img_time; last_image_time = cur_img_time;
+            return FIRST_IMAGE;
+        }
+        if (cur_img_time - last_image_time > 1.0 || cur_img_time < last_image_time) {     // :50-59 unstable camera stream
+            first_image_flag = true; last_image_time = 0; pub_count = 1; restarts++;
+            return RESTART;
+        }
+        last_image_time = cur_img_time;
+        // frequency control (:101-112)
+        bool PUB_THIS_FRAME;
+        if (std::round(1.0 * pub_count / (cur_img_time - first_image_time)) <= FREQ) {
+            PUB_THIS_FRAME = true;
+            if (std::abs(1.0 * pub_count / (cur_img_time - first_image_time) - FREQ) < 0.01 * FREQ) { first_image_time = cur_img_time; pub_count = 0; }
+        } else {
+            PUB_THIS_FRAME = false;
+        }
+        trackerData.PUB_THIS_FRAME = PUB_THIS_FRAME;
+        trackerData.readImage(img, cur_img_time);                                         // :139-140
+        for (unsigned int i = 0;; i++) if (!trackerData.updateID(i)) break;               // :155-164
+        if (!PUB_THIS_FRAME) return NOT_PUBLISHED;
+        pub_count++;                                                                      // :169
+        FeatureMsg msg;
+        msg.stamp = cur_img_time; msg.frame_id = "vins_body";                             // :177-178
+        std::set<int> hash_ids;
+        const auto& un_pts = trackerData.cur_un_pts; const auto& cur_pts = trackerData.cur_pts;
+        const auto& ids = trackerData.ids; const auto& pts_velocity = trackerData.pts_velocity;
+        for (unsigned int j = 0; j < ids.size(); j++) {
+            if (trackerData.track_cnt[j] > 1) {                                           // :189
+                const int p_id = ids[j];
+                hash_ids.insert(p_id);
+                msg.points.push_back(Point3f{un_pts[j].x, un_pts[j].y, 1.f});
+                msg.channels[0].push_back((float)(p_id * NUM_OF_CAM + 0));
+                msg.channels[1].push_back(cur_pts[j].x); msg.channels[2].push_back(cur_pts[j].y);
+                msg.channels[3].push_back(pts_velocity[j].x); msg.channels[4].push_back(pts_velocity[j].y);
+            }
+        }
+        msg.channels[5] = get_depth ? get_depth(cur_img_time, msg.points) : std::vector<float>(msg.points.size(), -1.f);   // :215-222
+        if (feature_points) *feature_points = std::move(msg);
+        if (!init_pub) { init_pub = true; return FIRST_PUBLISH_SUPPRESSED; }              // :225-231 no optical speed on the first image
+        return PUBLISHED;
+    }
+    FeatureTracker& trackerData;
+    int pub_count = 1;                          // feature_tracker_node.cpp:19
+private:
+    int FREQ;
+    bool first_image_flag = true, init_pub = false;
+    double first_image_time = 0.0, last_image_time = 0.0;
 };
 
 }  // namespace lvi_host

@@ -181,6 +181,11 @@ class LidarHotpath:
         k = np.ascontiguousarray(key_indices, np.int32)
         self.lib.check(self.lib.dll.lvi_map_assemble(self._h, k.ctypes.data_as(C.POINTER(C.c_int32)), len(k)), "lvi_map_assemble")
 
+    def map_update(self, key_indices):
+        """lvi_map_assemble's result maintained incrementally (keyframes entering / leaving the list)"""
+        k = np.ascontiguousarray(key_indices, np.int32)
+        self.lib.check(self.lib.dll.lvi_map_update(self._h, k.ctypes.data_as(C.POINTER(C.c_int32)), len(k)), "lvi_map_update")
+
     def scan_organize(self):
         self.lib.check(self.lib.dll.lvi_scan_organize(self._h), "lvi_scan_organize")
 

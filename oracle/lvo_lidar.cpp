@@ -760,6 +760,7 @@ void lvi_lidar_params_default(lvi_lidar_params* p)
     p->icp_max_iters = 20; p->icp_disable_break = 0;
     p->max_raw_points = 131072; p->max_map_points = 1 << 20; p->voxel_mode = 0;
     p->max_keyframes = 1024; p->max_keyframe_points = 1 << 22; p->map_on_main_stream = 0;
+    p->sector_handover_wait_us = 0; p->batch_scans = 1;
 }
 
 int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t /*device*/, lvi_lidar** out)
@@ -945,6 +946,9 @@ int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_key
     }
     return lvi_map_set(h, c.data(), (int32_t)tc, s.data(), (int32_t)ts);
 }
+
+// the reference has no incremental form: extractCloud fuses and re-filters the whole local map every scan (:931-965)
+int32_t lvi_map_update(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys) { return lvi_map_assemble(h, key_indices, n_keys); }
 
 int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)
 {

@@ -28,4 +28,12 @@ def oracle(pkg):
 @pytest.fixture(scope="session")
 def hip(pkg):
     """the product library; GPU tests fail loudly if it is missing"""
+    try:
+        # torch carries its own copy of the HIP runtime; it only finds the GPU when it initialises BEFORE the system
+        # runtime liblvi_hip.so is linked against (measured on the GPU box), and some tests use torch.cuda later
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
     return pkg.load_hip()

@@ -639,3 +639,136 @@ def test_replay_enqueue_matches_staged_path(pkg, oracle, hip, scene):
             assert np.abs(rr["pose"] - ro["pose"]).max() < 1e-4
             assert g2.counts() == g.counts()
     o.close(); g.close(); g2.close()
+
+
+# ----------------------------------------------------------------------------- BASELINE config 3 at full size
+@pytest.fixture(scope="module")
+def bench_map(pkg, hip):
+    """the raw local map of bench.py (BASELINE config 3: ~4.87 M points from 250 synthetic keyframes), from the same
+    generator and seed: the HIP handle extracts the keyframe features (bench.py ray-casts with torch on the GPU, here numpy)"""
+    S = pkg.synth
+    P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=1 << 16)
+    g = pkg.LidarHotpath(hip, **P)
+    mc, ms = S.make_map(g, 250, 30001, seed=4711, target_surf=5_000_000)
+    g.close()
+    assert len(ms) > 4_000_000
+    return mc, ms
+
+
+FULL = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=5_000_000 + 65536)
+
+
+def test_full_size_map_voxel_grids(pkg, oracle, hip, bench_map):
+    """the 4.87 M-point surf map through VoxelGrid(0.4) and the corner map through VoxelGrid(0.2): voxel idx per point, set of
+    occupied cells, points per cell and output order bit for bit; centroids inside count * 2^-23 * max|coord|"""
+    mc, ms = bench_map
+    o = pkg.LidarHotpath(oracle, **FULL); g = pkg.LidarHotpath(hip, **FULL)
+    assert _voxel_case(pkg, o, g, xyzi(ms), 0.4) > 50_000
+    assert _voxel_case(pkg, o, g, xyzi(mc), 0.2) > 1_000
+    o.close(); g.close()
+
+
+@pytest.mark.parametrize("fixed", [True, False], ids=["ten_fixed_iterations", "reference_break"])
+def test_full_size_scan_to_map(pkg, oracle, hip, bench_map, fixed):
+    """BASELINE config 3: 100 001-point scans against the bench's raw map, (a) 10 iterations with the break disabled (what
+    bench.py times) and (b) reference semantics (<= 20, break): DS counts exact, status / iteration count equal, pose within
+    1e-4 m / 1e-4 rad, selected counts within a few knife-edge features of ~15 000 (a feature whose weight s or plane
+    distance sits on its threshold follows the last bit of the pose; with identical inputs the test asserts that every
+    count moves by at most 0.1 % and that the poses agree)."""
+    S = pkg.synth
+    mc, ms = bench_map
+    kw = dict(FULL)
+    if fixed:
+        kw.update(icp_max_iters=10, icp_disable_break=1)
+    o = pkg.LidarHotpath(oracle, **kw); g = pkg.LidarHotpath(hip, **kw)
+    for h in (o, g):
+        h.map_upload(mc, ms); h.map_build()
+    co, cg = o.counts(), g.counts()
+    assert co["map_corner_ds"] == cg["map_corner_ds"] and co["map_surf_ds"] == cg["map_surf_ds"] > 50_000
+    worst = 0.0
+    for sid in range(3):                                         # bench.py's scan pool of rank 0: same poses, seeds, guesses
+        pose = S.loop_pose(0.37 + 0.71 * sid, 0.01 * np.sin(sid), -0.02 * np.cos(sid))
+        scan = S.make_scan(100001, pose, 12345 + sid)
+        guess = S.perturbed_guess(pose, sid)
+        for h in (o, g):
+            h.map_build()                                        # the reference re-voxelises and re-indexes per scan
+            h.scan_upload(scan); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+        co, cg = o.counts(), g.counts()
+        assert abs(co.pop("surf_ds") - cg.pop("surf_ds")) <= 3, (co, cg)     # second-stage grid: see test_parity_sweep_…
+        assert co == cg, (co, cg)
+        ro, rg = o.scan_match(guess), g.scan_match(guess)
+        assert ro["status"] == rg["status"] == 0
+        assert ro["iters"] == rg["iters"], (ro["iters"], rg["iters"])
+        if fixed:
+            assert rg["iters"] == 10
+        assert ro["degenerate"] == rg["degenerate"]
+        gap = max(abs(a - b) for a, b in zip(ro["n_sel"], rg["n_sel"]))
+        assert min(rg["n_sel"]) > 5000 and gap <= max(3, int(1e-3 * max(ro["n_sel"]))), (ro["n_sel"], rg["n_sel"])
+        dp = np.abs(ro["pose"] - rg["pose"])
+        assert dp[:3].max() < 1e-4 and dp[3:].max() < 1e-4, (sid, dp)
+        worst = max(worst, float(dp.max()))
+        assert np.abs(rg["pose"][3:] - pose[3:]).max() < 0.05 and np.abs(rg["pose"][:3] - pose[:3]).max() < 0.01
+    print(f"full-size scan-to-map ({'10 fixed' if fixed else 'reference'} iterations): worst |pose_hip - pose_oracle| = {worst:.2e}")
+    o.close(); g.close()
+
+
+# ----------------------------------------------------------------------------- sector pipeline robustness
+def test_sector_redo_path_gives_identical_bits(pkg, hip, scene):
+    """sector_handover_wait_us < 0: no pipelined sector workgroup ever waits for its predecessor, every one walks the ring
+    from sector 0 itself — the self-rescue of a workgroup whose producer is not resident.  Same bits as the pipeline."""
+    A = pkg._abi
+    out = []
+    for wait in (0, -1):
+        g = pkg.LidarHotpath(hip, sector_handover_wait_us=wait, **small_params())
+        rows = []
+        for rep in range(2):
+            g.scan_upload(scene["scan"]); g.scan_organize(); g.scan_extract()
+            n = g.counts()["n"]
+            rows.append((g.debug_get(A.DBG_CORNER_INDEX, np.int32), g.debug_get(A.DBG_LABEL, np.int32)[5:n - 5],
+                         g.debug_get(A.DBG_PICKED_FINAL, np.int32)[5:n - 5], xyzi(g.get_features()[1]).view(np.uint32).copy()))
+        out.append(rows)
+        g.close()
+    for ra, rb in zip(out[0], out[1]):
+        for x, y in zip(ra, rb):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_many_handles_in_flight(pkg, hip, scene):
+    """16 handles x 24 pipelined sector workgroups (each owning a CU's LDS) enqueued back to back on 16 streams: more waiting
+    consumers than the chip has CUs is survivable (bounded wait, then redo) and every handle returns the same record"""
+    H = 16
+    hs = [pkg.LidarHotpath(hip, icp_max_iters=4, icp_disable_break=1, **small_params(max_map_points=120000)) for _ in range(H)]
+    mc, ms = scene["map_corner"], scene["map_surf"][:100000]
+    for h in hs:
+        h.map_upload(mc, ms); h.map_build()
+    for h in hs:
+        h.sync()
+    for rep in range(3):
+        for h in hs:                                       # nothing synchronises between the handles
+            h.scan_upload(scene["scan"]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+            h.scan_match_async(scene["guess"], 0)
+    recs = [h.get_pose_record() for h in hs]
+    for r in recs:
+        assert r["status"] == 0 and r["iters"] == 4
+        np.testing.assert_array_equal(bits(r["pose"]), bits(recs[0]["pose"]))
+    for h in hs:
+        h.close()
+
+
+def test_device_error_reaches_the_async_record(pkg, hip, scene):
+    """a device-side error of a producer stage (here: a ring sector beyond the LDS-resident capacity) is carried by the
+    32-byte record of the async / replay path, not only by the host-fetch entry points"""
+    A = pkg._abi
+    S = pkg.synth
+    P = dict(N_SCAN=1, Horizon_SCAN=65536, max_raw_points=70000, max_map_points=400000, icp_max_iters=3, icp_disable_break=1)
+    g = pkg.LidarHotpath(hip, **P)
+    g.map_upload(scene["map_corner"], scene["map_surf"]); g.map_build()
+    scan = S.make_scan(60001, S.loop_pose(0.37, 0.01, -0.02), 5)
+    scan["line"] = 0                                            # one ring of 60 000 points: sectors of 10 000 > FEAT_SEG_CAP
+    g.scan_upload(scan); g.scan_organize(); g.scan_extract(); g.scan_downsample()
+    g.scan_match_async(scene["guess"], 0)
+    rec = np.zeros(8, np.float32)
+    code = hip.dll.lvi_get_pose_record(g._h, A._ptr(rec))       # fills the record, then reports the device status word
+    assert code == A.LVI_ERR_CAPACITY
+    assert int(rec[6:7].view(np.int32)[0]) == A.LVI_ERR_CAPACITY
+    g.close()
