@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — scans/sec of the lidar scan-matching hot path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one 100k-point synthetic MID360 scan per rank,
-reference-faithful: organise → feature extraction (incl. per-ring VoxelGrid) → scan VoxelGrid →
+One "step" = one pass of the hot path over one batch of 100k-point synthetic MID360 scans per rank,
+reference-faithful per scan: organise → feature extraction (incl. per-ring VoxelGrid) → scan VoxelGrid →
 re-voxelisation of the ≈5M-point raw local map + KNN index build (the reference rebuilds both
 for every scan: mapOptimization.cpp:958-965, 1322-1323) → 10 fixed Gauss-Newton iterations
 (convergence break disabled on GPU and CPU alike, SURVEY §8 d).  Inputs (raw scans, raw map)
 are resident in HBM before the timed region; the only host traffic inside it is the launch
-stream and one stream sync per step.
+stream and the event waits of the rolling replay.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Independent scans shard one-per-rank ("weak" scaling); the frozen map is broadcast once over
-RCCL and the 32-byte pose records are all-gathered over RCCL after every step.
+A step processes --inflight handles x --batch scans per rank: the scans of one handle go through ONE launch
+sequence (lvi_scan_batch_*, scan index in blockIdx.z).  Independent scans shard across ranks ("weak" scaling); the
+frozen raw map is broadcast once over RCCL and the 32-byte pose records are all-gathered over RCCL per step.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -29,37 +30,41 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+ROUND = "r02"                # profiles/<ROUND>_pmc_traffic.json carries this round's HBM counter traffic
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed windows of --steps steps each; `value` is the FIRST window (exactly --steps steps between fences), "
+                         "the others give value_windows (median / min / max)")
     ap.add_argument("--n-raw", type=int, default=100001)
     ap.add_argument("--keyframes", type=int, default=250)
     ap.add_argument("--kf-n-raw", type=int, default=30001)
     ap.add_argument("--map-points", type=int, default=5_000_000)
     ap.add_argument("--frozen-map", action="store_true", help="reuse the DS map/index across scans (not the headline)")
     ap.add_argument("--map-source", choices=["resident", "assemble"], default="resident",
-                    help="resident: the raw local map sits in HBM as one cloud (headline); assemble: it is fused per scan from the "
+                    help="resident: the raw local map sits in HBM as one cloud (headline); assemble: it is fused per step from the "
                          "device-resident keyframe store (SURVEY f-4: what a node does instead of uploading 78 MB per scan)")
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--pool", type=int, default=8, help="distinct scans per rank, cycled")
     ap.add_argument("--queue-depth", type=int, default=2,
-                    help="scans kept enqueued per handle in the rolling form (1 = sync a handle before its next scan)")
+                    help="steps kept enqueued per handle in the rolling form (0 = sync every handle after every step)")
     ap.add_argument("--inflight", type=int, default=4,
-                    help="independent scans in flight per GPU (BASELINE config 5: batched replay); each has its own handle, "
-                         "streams and map replica; a step processes this many scans per rank")
-    ap.add_argument("--enqueue", choices=["graph", "eager", "threads"], default="eager",
-                    help="how the per-scan launch sequence is issued: one hipGraph launch per scan, eager launches from one host "
-                         "thread, or eager launches from one host thread per in-flight scan (ctypes releases the GIL)")
+                    help="independent handles per GPU (own streams, own DS map / index replicas); with --batch S each carries S scans per step")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="scans per launch sequence (lvi_scan_batch_*): every kernel of the path carries the scan index in blockIdx.z. "
+                         "1 = the single-scan entry points")
+    ap.add_argument("--enqueue", choices=["graph", "eager"], default="eager",
+                    help="--batch 1 only: one hipGraph launch per scan instead of eager launches")
     ap.add_argument("--map-stream", type=int, default=-1, help="lvi_lidar_params.map_on_main_stream: -1 auto (1 when >= 4 scans in flight), 0, 1")
-    ap.add_argument("--step-sync", action="store_true",
-                    help="synchronise every handle at the end of each step instead of only before a handle is reused")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-tracker", action="store_true")
+    ap.add_argument("--tracker-seconds", type=float, default=0.6)
     ap.add_argument("--profile-steps", type=int, default=5)
     return ap.parse_args()
 
@@ -86,15 +91,16 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     pkg = graft.import_package()
-    A, S = pkg._abi, pkg.synth
+    A, S, R = pkg._abi, pkg.synth, pkg.replay
     hip = pkg.load_hip()                      # raises when the HIP library is missing: no fallback
 
+    B = max(1, args.inflight)
+    NB = max(1, min(args.batch, 8))
     P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=args.map_points + 65536,
-             icp_max_iters=args.icp_iters, icp_disable_break=1,
-             map_on_main_stream=(1 if args.inflight >= 4 else 0) if args.map_stream < 0 else args.map_stream,   # one stream per hardware queue once >= 4 scans are in flight
+             icp_max_iters=args.icp_iters, icp_disable_break=1, batch_scans=NB,
+             map_on_main_stream=(1 if B * NB >= 4 else 0) if args.map_stream < 0 else args.map_stream,   # one stream per hardware queue once >= 4 scans are in flight
              max_keyframes=(args.keyframes + 8) if args.map_source == "assemble" else 0,
              max_keyframe_points=(args.map_points + 200000) if args.map_source == "assemble" else 0)
-    B = max(1, args.inflight)
     hs = [pkg.LidarHotpath(hip, device=local_rank, **P) for _ in range(B)]
     g = hs[0]
 
@@ -118,7 +124,7 @@ def main():
     torch.cuda.synchronize()
     keys = None
     if args.map_source == "assemble":
-        # SURVEY f-4: the local map is not handed over as one raw cloud but fused on the device, per scan, from the
+        # SURVEY f-4: the local map is not handed over as one raw cloud but fused on the device, per step, from the
         # keyframe store (here: the same points cut into --keyframes pieces, stored with the identity pose, so the
         # fused map — and therefore every result — is bit-identical to the resident-map run)
         hc, hsurf = d_mc.cpu().numpy(), d_ms.cpu().numpy()
@@ -162,75 +168,45 @@ def main():
         sc = S.make_scan(args.n_raw, pose, 12345 + sid, torch_device=dev)
         poses.append(pose); guesses.append(S.perturbed_guess(pose, sid)); scans_host.append(sc)
         d_scans.append(torch.from_numpy(sc.view(np.uint8).reshape(-1, 20).copy()).to(dev))
-    total = args.warmup + args.steps + args.profile_steps
-    d_rec = torch.zeros((total * B, 8), dtype=torch.float32, device=dev)
+    n_windows = max(1, args.repeats)
+    total = args.warmup + n_windows * args.steps + args.profile_steps
+    per_step = B * NB                                                 # scans per step and rank
+    d_rec = torch.zeros((total * per_step, 8), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=B) if args.enqueue == "threads" and B > 1 else None
-
     enq = [0.0]
+    rebuild = not args.frozen_map
 
-    rolling = args.enqueue in ("eager", "threads") and not args.step_sync
-    depth = max(1, min(args.queue_depth, 8))
-    pending = []              # rolling mode: steps whose records have not been gathered yet
-
-    def step(i):
+    def issue(i, b, h):
+        """enqueue one handle's share of step i: NB consecutive scans of the pool, no synchronisation"""
         t_e = time.perf_counter()
-        # B independent scans in flight.  Rolling form (default): a handle is synchronised only right before it gets its
-        # next scan, so while the host enqueues handle 0's scan of step i+1 the other handles are still busy with step i —
-        # no queue ever waits for the host to finish enqueueing its neighbours.  (--step-sync: enqueue all, then sync all.)
-        def one(b):
-            h = hs[b]
-            k = (i * B + b) % args.pool
-            if rolling:
-                # at most --queue-depth scans enqueued per handle: wait for the one issued `depth` steps ago (depth 1 = the
-                # handle is idle while the host prepares its next scan; depth 2 keeps its queue fed)
-                h.wait_mark(i % depth)
-            if args.enqueue == "graph":
-                # one C-ABI call per scan: D2D of the 2 MB scan + one hipGraph launch of the whole path
-                h.scan_replay_enqueue(d_scans[k].data_ptr(), args.n_raw, guesses[k], d_rec[i * B + b].data_ptr(), rebuild_map=not args.frozen_map)
-            else:
-                if not args.frozen_map:
-                    if keys is not None:
-                        h.map_assemble(keys)                              # fuse the keyframes, then the build (f-4)
-                    else:
-                        h.map_build()                                     # own stream: overlaps the scan-side stages
-                h.scan_upload_device(d_scans[k].data_ptr(), args.n_raw)   # D2D, 2 MB
-                h.scan_organize(); h.scan_extract(); h.scan_downsample()
-                h.scan_match_async(guesses[k], d_rec[i * B + b].data_ptr())
-            if rolling:
-                h.mark(i % depth)
-            if args.enqueue == "threads" and not rolling:
-                h.sync()
-        if args.enqueue == "threads" and B > 1:
-            list(pool.map(one, range(B)))
+        base = (i * B + b) * NB
+        ks = [R.scan_index(i, b, z, B, NB, args.pool) for z in range(NB)]
+        if NB == 1 and args.enqueue == "graph":
+            # one C-ABI call per scan: D2D of the 2 MB scan + one hipGraph launch of the whole path
+            h.scan_replay_enqueue(d_scans[ks[0]].data_ptr(), args.n_raw, guesses[ks[0]], d_rec[base].data_ptr(), rebuild_map=rebuild)
+        elif NB == 1:
+            if rebuild:
+                if keys is not None:
+                    h.map_assemble(keys)                              # fuse the keyframes, then the build (f-4)
+                else:
+                    h.map_build()
+            h.scan_upload_device(d_scans[ks[0]].data_ptr(), args.n_raw)   # D2D, 2 MB
+            h.scan_organize(); h.scan_extract(); h.scan_downsample()
+            h.scan_match_async(guesses[ks[0]], d_rec[base].data_ptr())
         else:
-            for b in range(B):
-                one(b)
+            if rebuild and keys is not None:
+                h.map_assemble(keys)                                  # fuses the raw map once per step and rebuilds every slot's DS map + index
+            h.batch_bind_device([d_scans[k].data_ptr() for k in ks], [args.n_raw] * NB)      # scans are read in place
+            h.batch_run(np.stack([guesses[k] for k in ks]), d_rec[base].data_ptr(), rebuild_map=rebuild and keys is None)
         enq[0] += time.perf_counter() - t_e
-        if rolling:
-            # every handle waited above for its scan of step i-depth before the new one went in: those records are final
-            pending.append(i)
-            if len(pending) > depth:
-                j = pending.pop(0)
-                if world > 1:
-                    pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
-            return
-        for h in hs:
-            h.sync()
-        if world > 1:
-            pkg.replay.gather_records(d_rec[i * B:(i + 1) * B], world, dist)   # RCCL all_gather: 32 B pose record per scan
 
-    def flush():
-        """rolling mode: finish the step still in flight and gather its records (inside the timed region)"""
-        for h in hs:
-            h.sync()
-        while pending:
-            j = pending.pop(0)
-            if rolling and world > 1:
-                pkg.replay.gather_records(d_rec[j * B:(j + 1) * B], world, dist)
+    def gather(j):
+        if world > 1:
+            R.gather_records(d_rec[j * per_step:(j + 1) * per_step], world, dist)   # RCCL all_gather: 32 B pose record per scan
+
+    roll = R.RollingReplay(hs, issue, gather, depth=args.queue_depth)
 
     def fence():
         torch.cuda.synchronize()
@@ -239,59 +215,82 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
-    flush()
+        roll.step(i)
+    roll.flush()
     fence()
-    enq[0] = 0.0
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
-    flush()
-    fence()
-    elapsed = time.perf_counter() - t0
-    enqueue_ms_per_scan = 1e3 * enq[0] / (args.steps * B)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
+    win = []
+    enq_first = 0.0
+    for w in range(n_windows):
+        enq[0] = 0.0
+        t0 = time.perf_counter()
+        first = args.warmup + w * args.steps
+        for i in range(first, first + args.steps):
+            roll.step(i)
+        roll.flush()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax[0])
+        win.append(el)
+        if w == 0:
+            enq_first = enq[0]
+    elapsed = win[0]
+    enqueue_ms_per_scan = 1e3 * enq_first / (args.steps * per_step)
+    rates = [world * per_step * args.steps / e for e in win]
 
-    # ---------------------------------------------------------------- sanity of what was timed (every record, vs ground truth)
-    rec = d_rec[args.warmup * B:(args.warmup + args.steps) * B].cpu().numpy()
+    # ---------------------------------------------------------------- sanity of what was timed (every record of every window, vs ground truth)
+    lo, hi = args.warmup * per_step, (args.warmup + n_windows * args.steps) * per_step
+    rec = d_rec[lo:hi].cpu().numpy()
     status = rec[:, 6].copy().view(np.int32)
     iters = rec[:, 7].copy().view(np.int32)
-    gt = np.array([poses[j % args.pool] for j in range(args.warmup * B, (args.warmup + args.steps) * B)])
+    pool_idx = np.array([j % args.pool for j in range(lo, hi)])
+    gt = np.array([poses[k] for k in pool_idx])
     err_t = float(np.abs(rec[:, 3:6] - gt[:, 3:6]).max())
     err_r = float(np.abs(rec[:, 0:3] - gt[:, 0:3]).max())
     ok = bool((status == 0).all() and (iters == args.icp_iters).all() and err_t < 0.05 and err_r < 0.01)
+    # the same scan gives the same bits whichever handle, slot or step processed it
+    for k in range(args.pool):
+        rows = rec[pool_idx == k]
+        if len(rows):
+            ok = ok and bool((rows.view(np.uint32) == rows[0].view(np.uint32)).all())
 
-    # ---------------------------------------------------------------- tracker leg (secondary metric: LK frames/sec)
+    # ---------------------------------------------------------------- tracker leg (secondary metric: LK frames/sec), frame pairs sharded over the ranks
     # (runs before the profiled pass: measured on this runtime, once a pass with HIP timing events has run in the process,
     # every later 0.9 MB frame upload of the tracker takes ~1 ms instead of ~40 us)
     tracker_out = None
-    if not args.no_tracker and rank == 0:
+    if not args.no_tracker:
         try:
-            tracker_out = bench_tracker(pkg, hip, local_rank)
+            tracker_out = bench_tracker(pkg, hip, local_rank, rank, world, dist if world > 1 else None, dev, args.tracker_seconds)
         except Exception as e:                      # noqa: BLE001 — the tracker leg must not hide the headline
             tracker_out = dict(error=str(e))
 
     # ---------------------------------------------------------------- per-kernel timing with HIP events (same workload, same process)
-    # (only handle 0 records events; the other in-flight scans keep running beside it as in the timed pass)
-    g.prof_reset(); g.prof_enable(True)
-    for i in range(args.warmup + args.steps, total):
-        step(i)
-    flush()
-    stats = g.prof_read()
-    g.prof_enable(False)
+    # (only handle 0 records events; the other handles keep running beside it as in the timed pass)
+    stats, kern_ms = [], 0.0
+    if args.profile_steps > 0:
+        g.prof_reset(); g.prof_enable(True)
+        for i in range(args.warmup + n_windows * args.steps, total):
+            roll.step(i)
+        roll.flush()
+        stats = g.prof_read()
+        g.prof_enable(False)
+    cnt = g.counts()
+    Q = cnt["corner_ds"] + cnt["surf_ds"]
     for s in stats:
         s["avg_us"] = 1e3 * s["total_ms"] / max(s["launches"], 1)
+        if s["name"] == "icp_residual":
+            # the library books a nominal 128 * 0.25 * n_raw per scan; the real query count is known here (read back above)
+            s["bytes_alg"] = 128.0 * Q * NB * s["launches"]
         s["gbs"] = round((s["bytes_alg"] / s["launches"]) / (s["avg_us"] * 1e-6) / 1e9, 1) if s["bytes_alg"] > 0 else None
     stats.sort(key=lambda s: -s["total_ms"])
     kern_ms = sum(s["total_ms"] for s in stats) / max(args.profile_steps, 1)
-    traffic_tab = {}
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    traffic_tab, traffic_src = {}, None
+    tpath = os.path.join(ROOT, "profiles", ROUND + "_pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic_tab = json.load(open(tpath))
+            traffic_tab = json.load(open(tpath)); traffic_src = os.path.relpath(tpath, ROOT)
         except Exception:
             traffic_tab = {}
 
@@ -299,47 +298,66 @@ def main():
         b = s["bytes_alg"] / s["launches"]
         gbs = b / (s["avg_us"] * 1e-6) / 1e9
         base = s["name"].split("/")[0] + "_kernel"
-        # profiles/r01_pmc_traffic.json is keyed "kernel [grid G, wg W]" (separate rocprofv3 --pmc passes of this same
-        # command, tools/summarize_prof.py pmc); the profiled tags with bytes are the largest geometry of their kernel
+        # keyed "kernel [grid G, wg W]" (separate rocprofv3 --pmc passes of this same command, tools/summarize_prof.py pmc);
+        # the profiled tags with bytes are the largest geometry of their kernel
         cand = [v["hbm_bytes_per_launch"] for k, v in traffic_tab.items() if k.startswith(base + " ")]
         tr = max(cand) if cand else None
         return dict(bound="hbm", kernel=s["name"], achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                     measured_copy_gbs=copy_gbs, frac_of_measured_copy=(round(gbs / copy_gbs, 4) if copy_gbs else None),
-                    traffic=tr, bytes_alg_per_launch=b, avg_launch_us=round(s["avg_us"], 2), launches_per_scan=s["launches"] / max(args.profile_steps, 1),
-                    note=note)
+                    traffic=tr, traffic_source=(traffic_src if tr is not None else "no PMC pass of this round's build committed yet: null, not a stale figure"),
+                    bytes_alg_per_launch=b, scans_per_launch=NB, avg_launch_us=round(s["avg_us"], 2),
+                    launches_per_step=s["launches"] / max(args.profile_steps, 1), note=note)
 
     roofline = None
     roofline_bw = None
     with_bytes = [s for s in stats if s["bytes_alg"] > 0]
     if with_bytes:
-        # dominant kernel = largest total time per scan among the kernels of the path
-        roofline = roof(with_bytes[0], "HIP events on the launch stream of one of the in-flight scans, profiled pass of the same workload right "
-                                       "after the timed pass; the kernel with the largest total time per scan.  When that kernel is icp_residual: "
-                                       "it is VALU-issue bound on an index that stays in L2 (clock64 phase stamps, DESIGN.md 5), so its HBM "
-                                       "fraction is small by construction; the HBM-bound part of the path is in roofline_streaming_kernel")
-        # the path's algorithmic bytes are dominated by the per-scan map re-voxelisation: its widest streaming kernel
+        # dominant kernel = largest total time per step among the kernels of the path
+        roofline = roof(with_bytes[0], "HIP events on the launch stream of one of the handles, profiled pass of the same workload right "
+                                       "after the timed windows; the kernel with the largest total time per step.  icp_residual is VALU-issue "
+                                       "bound on an index that stays in L2 (clock64 phase stamps, DESIGN.md 5): its HBM fraction is small by "
+                                       "construction; bytes = 128 B x the real query count read back from the device")
         stream = max(with_bytes, key=lambda s: s["bytes_alg"] / s["launches"] if s["avg_us"] > 0 else 0)
         big = [s for s in with_bytes if s["bytes_alg"] / s["launches"] >= 0.5 * stream["bytes_alg"] / stream["launches"]]
         roofline_bw = roof(max(big, key=lambda s: s["total_ms"]), "the HBM-streaming kernel with the largest total time (map re-voxelisation)")
-    cnt = g.counts()
+
+    # ---------------------------------------------------------------- whole-path roofline: SURVEY 8(d) formulas with the measured counts
+    N, n = args.n_raw - 1, cnt["n"]
+    C0, S1, Cd, Sd = cnt["corner"], cnt["surf"], cnt["corner_ds"], cnt["surf_ds"]
+    Mraw, Mds = nc + ns, cnt_map["map_corner_ds"] + cnt_map["map_surf_ds"]
+    path_bytes = dict(organize=20 * N + 24 * n, smooth_occlusion=16 * n, sector_pick_collect=8 * n + 16 * n + 16 * n,
+                      ring_ds=16 * n + 16 * S1, scan_ds=16 * (C0 + S1) + 16 * (Cd + Sd),
+                      map_ds=(16 * Mraw + 16 * Mds) if rebuild else 0, grid_build=36 * Mds if rebuild else 0,
+                      gn_iterations=128 * Q * args.icp_iters)
+    bytes_scan = float(sum(path_bytes.values()))
+    path_gbs = bytes_scan * rates[0] / 1e9
+    roofline_path = dict(bound="hbm", achieved=round(path_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(path_gbs / HBM_PEAK_GBS, 4),
+                         frac_of_measured_copy=(round(path_gbs / copy_gbs, 4) if copy_gbs else None), bytes_per_scan=bytes_scan, stages=path_bytes,
+                         note="SURVEY 8(d): compulsory bytes per scan (each input read once, each output written once, measured counts) x scans/s")
 
     out = dict(
-        metric="scans_per_sec_100k_mid360", value=round(world * B * args.steps / elapsed, 2), unit="scans/s",
+        metric="scans_per_sec_100k_mid360", value=round(rates[0], 2), unit="scans/s",
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
         higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
         config=dict(workload=("lidar_odometry scan-to-map, reference-faithful per scan: organise + LOAM feature extraction + voxel grids "
                               "+ re-voxelisation of the raw local map + KNN index build + %d GN iterations" % args.icp_iters)
-                    if not args.frozen_map else "lidar_odometry scan-to-map with a frozen downsampled map (DS + index reused)",
-                    n_raw=args.n_raw, map_raw_points=nc + ns, map_ds_points=cnt_map["map_corner_ds"] + cnt_map["map_surf_ds"],
-                    scan_features=dict(corner=cnt["corner"], surf=cnt["surf"], corner_ds=cnt["corner_ds"], surf_ds=cnt["surf_ds"]),
-                    icp_iters=args.icp_iters, map_source=args.map_source, scans_in_flight_per_gpu=B, scans_per_step=world * B, enqueue=args.enqueue, queue_depth=(depth if rolling else 1),
-                    handle_sync="per step" if not rolling else "per handle: before enqueueing a scan, wait for the one issued queue_depth steps earlier",
-                    sharding="independent scans sharded across ranks (B in flight per rank), RCCL all_gather of pose records per step"),
-        roofline=roofline, roofline_streaming_kernel=roofline_bw,
+                    if rebuild else "lidar_odometry scan-to-map with a frozen downsampled map (DS + index reused)",
+                    n_raw=args.n_raw, map_raw_points=nc + ns, map_ds_points=Mds,
+                    scan_features=dict(corner=C0, surf=S1, corner_ds=Cd, surf_ds=Sd),
+                    icp_iters=args.icp_iters, map_source=args.map_source, handles_per_gpu=B, scans_per_launch_sequence=NB,
+                    scans_in_flight_per_gpu=B * NB * max(args.queue_depth, 1), scans_per_step=world * per_step,
+                    enqueue=args.enqueue if NB == 1 else "batched", queue_depth=roll.depth,
+                    handle_sync="per step" if not roll.depth else "per handle: before enqueueing a step, wait for the one issued queue_depth steps earlier",
+                    sharding="independent scans sharded across ranks, RCCL all_gather of pose records per step"),
+        value_windows=dict(n=n_windows, steps_each=args.steps, scans_per_sec=dict(median=round(float(np.median(rates)), 2), min=round(min(rates), 2),
+                                                                                    max=round(max(rates), 2), all=[round(r, 1) for r in rates]),
+                           window_s=[round(e, 4) for e in win],
+                           note="`value` is window 0 alone (exactly --steps steps between fences); the others repeat it back to back"),
+        roofline=roofline, roofline_streaming_kernel=roofline_bw, roofline_path=roofline_path,
         results_ok=ok, pose_err_vs_truth=dict(trans_m=err_t, rot_rad=err_r),
         kernel_time_ms_per_step=round(kern_ms, 4), host_enqueue_ms_per_scan=round(enqueue_ms_per_scan, 4),
-        top_kernels=[dict(name=s["name"], launches_per_scan=s["launches"] / max(args.profile_steps, 1), avg_us=round(s["avg_us"], 2), gbs=s["gbs"])
-                     for s in stats[:12]],
+        top_kernels=[dict(name=s["name"], launches_per_step=s["launches"] / max(args.profile_steps, 1), avg_us=round(s["avg_us"], 2), gbs=s["gbs"])
+                     for s in stats[:14]],
         setup_s=round(setup_s, 1),
     )
     if tracker_out is not None:
@@ -349,7 +367,8 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu:
         from oracle import loader
         ora = loader.load(pkg)
-        o = pkg.LidarHotpath(ora, **P)
+        Po = dict(P); Po["batch_scans"] = 1
+        o = pkg.LidarHotpath(ora, **Po)
         o.map_upload(mc, ms)
         times = []
         ora_res = {}                                      # pool index -> the oracle's result for that scan (parity_vs_oracle)
@@ -358,7 +377,7 @@ def main():
         while True:
             t1 = time.perf_counter()
             o.scan_upload(scans_host[k % args.pool]); o.scan_organize(); o.scan_extract(); o.scan_downsample()
-            if not args.frozen_map or k == 0:
+            if rebuild or k == 0:
                 o.map_build()
             r_o = o.scan_match(guesses[k % args.pool])
             ora_res.setdefault(k % args.pool, r_o)
@@ -378,7 +397,7 @@ def main():
         # scan the oracle leg reached; bar of BASELINE.json: 1e-4 m / 1e-4 rad, status and iteration count equal)
         dm, dr, same, npar = 0.0, 0.0, True, 0
         for j in range(len(rec)):
-            kk = (args.warmup * B + j) % args.pool
+            kk = int(pool_idx[j])
             if kk not in ora_res:
                 continue
             ro = ora_res[kk]
@@ -391,7 +410,6 @@ def main():
         if isinstance(out.get("tracker"), dict) and "value" in out["tracker"]:
             # the same LK step on the oracle (scalar, single-threaded restatement of OpenCV's calcOpticalFlowPyrLK; a real
             # OpenCV build would use SIMD and its thread pool — SURVEY 8d caveat)
-            S = pkg.synth
             w, h = 1280, 720
             img0 = S.make_texture(w, h, 4242)
             img1 = S.warp_homography(img0, S.small_motion_homography(w, h, 100))
@@ -411,35 +429,80 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_tracker(pkg, hip, device):
-    """LK frames/sec at 1280x720, 150 features, 4 pyramid levels (config 4 of BASELINE.json)"""
-    S = pkg.synth
+def bench_tracker(pkg, hip, device, rank, world, dist, dev, seconds):
+    """LK frames/sec at 1280x720, 150 features, 4 pyramid levels (config 4 of BASELINE.json).  Frame pair i belongs to rank
+    i mod world; every rank tracks its share for >= `seconds`, the per-rank rates are gathered and summed."""
+    import torch
+    S, R = pkg.synth, pkg.replay
     w, h = 1280, 720
     img0 = S.make_texture(w, h, 4242)
-    frames = [img0] + [S.warp_homography(img0, S.small_motion_homography(w, h, 100 + i)) for i in range(4)]
+    n_frames = 5
+    frames = [img0] + [S.warp_homography(img0, S.small_motion_homography(w, h, 100 + i)) for i in range(n_frames - 1)]
     t = pkg.TrackerHotpath(hip, device=device, max_width=w, max_height=h)
     pts = t.good_features(img0, 150, 0.01, 20.0)
+    # pair p = (frame p mod 5, frame (p+1) mod 5); this rank's pairs, cycled until the time budget is spent
+    mine = R.shard_frames(40 * world, rank, world)
     t.push_image(frames[0])
-    n_iter, t_total = 40, 0.0
+    n_done, t_total = 0, 0.0
     parts = [0.0, 0.0, 0.0]
-    for i in range(n_iter + 5):
-        f = frames[(i + 1) % 5]                      # the previous push is "cur", this one becomes "forw"
+    warm = 5
+    it = 0
+    while True:
+        p = mine[it % len(mine)]
+        f = frames[(p + 1) % n_frames]                      # the previous push is "cur", this one becomes "forw"
         t0 = time.perf_counter()
         t.push_image(f); t1 = time.perf_counter(); t.set_points(pts); t2 = time.perf_counter(); t.run_lk(); t.sync()
-        if i >= 5:
-            t_total += time.perf_counter() - t0
-            parts[0] += t1 - t0; parts[1] += t2 - t1; parts[2] += time.perf_counter() - t2
+        t3 = time.perf_counter()
+        if it >= warm:
+            t_total += t3 - t0; n_done += 1
+            parts[0] += t1 - t0; parts[1] += t2 - t1; parts[2] += t3 - t2
+        it += 1
+        if it >= warm and t_total >= seconds and n_done >= 40:
+            break
     xy, st, _ = t.get_lk()
+    rate = n_done / t_total
     # Shi-Tomasi on the current frame (goodFeaturesToTrack, 150 corners, no mask), device-resident image
     t.set_mask(None); t.run_gftt(150); t.sync()
     t0 = time.perf_counter()
-    for i in range(20):
+    n_g = 0
+    while n_g < 20 or time.perf_counter() - t0 < 0.2:
+        t.run_gftt(150); n_g += 1
+    t.sync()
+    gftt_us = 1e6 * (time.perf_counter() - t0) / n_g
+    # per-kernel HIP events of the tracker chain (one frame pair + one GFTT), for the tracker roofline
+    t.prof_reset(); t.prof_enable(True)
+    for i in range(8):
+        t.push_image(frames[(i + 1) % n_frames]); t.set_points(pts); t.run_lk()
         t.run_gftt(150)
     t.sync()
-    gftt_us = 1e6 * (time.perf_counter() - t0) / 20
-    return dict(metric="lk_frames_per_sec_1280x720_150pts", value=round(n_iter / t_total, 1), unit="frames/s",
+    ks = t.prof_read(); t.prof_enable(False)
+    kt = {k["name"]: 1e3 * k["total_ms"] / 8.0 for k in ks}                  # us per frame, per kernel
+    lk_us = sum(v for k, v in kt.items() if k.startswith(("pyrdown", "lk_", "clahe")))
+    gf_us = sum(v for k, v in kt.items() if not k.startswith(("pyrdown", "lk_", "clahe")))
+    lk_bytes, gf_bytes = 2.1e6, 1.85e6                       # SURVEY 8(d): per LK frame pair / per GFTT frame
+    total_rate = rate
+    per_rank = [rate]
+    if world > 1:
+        tr = torch.tensor([rate], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(tr) for _ in range(world)]
+        dist.all_gather(allr, tr)
+        per_rank = [float(x[0]) for x in allr]
+        total_rate = float(sum(per_rank))
+    t.close()
+
+    def rl(nbytes, us, note):
+        if not us:
+            return None
+        gbs = nbytes / (us * 1e-6) / 1e9
+        return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5), bytes_alg=nbytes,
+                    kernel_us=round(us, 1), note=note)
+    return dict(metric="lk_frames_per_sec_1280x720_150pts", value=round(total_rate, 1), unit="frames/s", per_rank=[round(r, 1) for r in per_rank],
+                frames_timed=n_done, seconds_timed=round(t_total, 3), sharding="frame pair i -> rank i mod world",
                 tracked=int(st.sum()), features=int(len(pts)), note="includes the H2D of each new 0.92 MB frame", gftt_us_per_frame=round(gftt_us, 1),
-                us_per_frame=dict(push_image=round(1e6 * parts[0] / n_iter, 1), set_points=round(1e6 * parts[1] / n_iter, 1), lk_and_sync=round(1e6 * parts[2] / n_iter, 1)))
+                us_per_frame=dict(push_image=round(1e6 * parts[0] / n_done, 1), set_points=round(1e6 * parts[1] / n_done, 1), lk_and_sync=round(1e6 * parts[2] / n_done, 1)),
+                kernel_us_per_frame={k: round(v, 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1])},
+                roofline_lk=rl(lk_bytes, lk_us, "SURVEY 8(d): 2.1 MB per LK frame pair / sum of the pyramid + LK kernel times (HIP events): latency-bound, 150 wavefronts"),
+                roofline_gftt=rl(gf_bytes, gf_us, "SURVEY 8(d): 1.85 MB per GFTT frame / sum of the min-eig, compaction, sort and pick kernel times"))
 
 
 if __name__ == "__main__":

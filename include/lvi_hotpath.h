@@ -264,6 +264,27 @@ int32_t lvi_map_upload_device(lvi_lidar *h, const void *d_corner_raw, int32_t nc
  * once into a hipGraph per (n_raw, map size, rebuild_map) and replayed, so a call costs one graph launch. */
 int32_t lvi_scan_replay_enqueue(lvi_lidar *h, const void *d_pts, int32_t n_raw, const float pose_init[6], void *d_record, int32_t rebuild_map);
 
+/* ---- batched form [hip: one launch sequence for the whole batch; oracle: a loop] ---------------------------------
+ * Up to lvi_lidar_params.batch_scans independent scans (slots 0 .. n_scans-1) go through organise → features → scan
+ * DS → [per-slot re-voxelisation + re-indexing of the handle's raw local map when rebuild_map != 0, as the reference
+ * does for every scan, mapOptimization.cpp:958-965, 1322-1323] → scan matching SIDE BY SIDE: every kernel of the path
+ * carries the slot in blockIdx.z, so the batch costs the launches of one scan and the one-workgroup links of the
+ * dependent chain (scans, the 6x6 solves) run n_scans workgroups wide.  Results are bit-identical to the single-scan
+ * entry points.  The raw local map (lvi_map_upload* / lvi_map_assemble) is shared by the slots; lvi_map_build builds every
+ * slot's DS map and index.  n_raw[z] = Msg.point_num of scan z (the final point is dropped, imageProjection.cpp:249). */
+/* scans already in HBM, read in place (no copy): the buffers must stay valid until the batch has run */
+int32_t lvi_scan_batch_bind_device(lvi_lidar *h, int32_t n_scans, const void *const *d_pts, const int32_t *n_raw);
+/* scans in host memory (copied through pinned staging, no stream sync) */
+int32_t lvi_scan_batch_upload(lvi_lidar *h, int32_t n_scans, const lvi_livox_pt *const *pts, const int32_t *n_raw);
+/* enqueue the path for the bound / uploaded scans from pose_init[z][6] (imu_available = 0); slot z's 32-byte pose record
+ * goes to d_records + 32 z (device pointer, may be NULL).  No host sync.  A device-side error of a slot travels in its
+ * record's status. */
+int32_t lvi_scan_batch_run(lvi_lidar *h, int32_t n_scans, const float *pose_init, void *d_records, int32_t rebuild_map);
+/* wait for the batch and copy the records of slots 0 .. n_scans-1 to the host */
+int32_t lvi_scan_batch_get_records(lvi_lidar *h, int32_t n_scans, lvi_pose_record *out);
+/* [hip only] the slot the fetch / inspection entry points below (and the single-scan stage calls) address; default 0 */
+int32_t lvi_batch_select(lvi_lidar *h, int32_t slot);
+
 /* fetch current stage outputs (host buffers) */
 int32_t lvi_get_scan_info(lvi_lidar *h, lvi_scan_info *out);
 int32_t lvi_get_features(lvi_lidar *h, lvi_cloud *corner, lvi_cloud *surf);       /* cornerCloud, surfaceCloud */

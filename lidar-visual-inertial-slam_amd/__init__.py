@@ -8,7 +8,7 @@ import it through ``__graft_entry__.import_package()`` (module name
 """
 import os
 
-from . import _abi, replay, synth  # noqa: F401
+from . import _abi, host_api, replay, synth  # noqa: F401
 from ._abi import Library, LviError, PT_DTYPE, LIVOX_DTYPE  # noqa: F401
 from .lidar import LidarHotpath, default_params  # noqa: F401
 from .tracker import TrackerHotpath, default_tracker_params  # noqa: F401
@@ -28,3 +28,14 @@ def load_hip():
         if _hip.backend != "hip-gfx950":
             raise RuntimeError(f"{HIP_LIB_PATH} reports backend {_hip.backend!r}")
     return _hip
+
+
+_host = None
+
+
+def load_host():
+    """host/liblvi_host_hip.so: the C++ host mirror over the product library (built by build.py)"""
+    global _host
+    if _host is None:
+        _host = host_api.HostLibrary(host_api.HOST_HIP_LIB)
+    return _host

@@ -133,6 +133,11 @@ SIGNATURES = {
     "lvi_scan_upload_device": (_i32, [_vp, _vp, _i32]),
     "lvi_map_upload_device": (_i32, [_vp, _vp, _i32, _vp, _i32]),
     "lvi_scan_replay_enqueue": (_i32, [_vp, _vp, _i32, _P(_f32), _vp, _i32]),
+    "lvi_scan_batch_bind_device": (_i32, [_vp, _i32, _P(_vp), _P(_i32)]),
+    "lvi_scan_batch_upload": (_i32, [_vp, _i32, _P(_vp), _P(_i32)]),
+    "lvi_scan_batch_run": (_i32, [_vp, _i32, _P(_f32), _vp, _i32]),
+    "lvi_scan_batch_get_records": (_i32, [_vp, _i32, _vp]),
+    "lvi_batch_select": (_i32, [_vp, _i32]),
     "lvi_get_scan_info": (_i32, [_vp, _P(ScanInfo)]),
     "lvi_get_features": (_i32, [_vp, _P(Cloud), _P(Cloud)]),
     "lvi_get_scan_ds": (_i32, [_vp, _P(Cloud), _P(Cloud)]),

@@ -51,5 +51,13 @@ def build_hip(force=False, verbose=False):
     return OUT
 
 
+def build_host(verbose=False):
+    """host/liblvi_host_hip.so: the C++ host mirror (host/lvi_host.hpp) flattened to C, linked against liblvi_hip.so"""
+    from .host_api import HOST_HIP_LIB, build_host_library
+    if verbose:
+        print("g++ -shared host/lvi_seq_capi.cpp -llvi_hip ->", HOST_HIP_LIB, flush=True)
+    return build_host_library(HOST_HIP_LIB, CSRC, "lvi_hip")
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))

@@ -3,6 +3,7 @@
 // compute entry point enqueues HIP kernels or fails.
 #include <algorithm>
 #include <cmath>
+#include <memory>
 
 #include "lvi_lidar.hpp"
 
@@ -52,7 +53,11 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
 using namespace lvi;
 
 struct lvi_lidar {
-    LidarDev d;
+    LidarDev d;                                     // slot 0: owns the streams, the profiler, the keyframe store and the raw map
+    std::vector<std::unique_ptr<LidarDev>> more;    // batch slots 1 .. batch_scans-1 (lvi_scan_batch_*)
+    std::vector<LidarDev*> slots;                   // [batch_scans] = &d, more[0], …
+    int sel = 0;                                    // slot the fetch / inspection entry points read (lvi_batch_select)
+    LidarDev& cur() { return *slots[sel]; }
     std::vector<int32_t> vkeys, vcells, vcounts;    // debug of the last lvi_voxel_downsample
     bool have_icp_host = false;
 };
@@ -185,15 +190,27 @@ int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(LVI_ERR_NO_DEVICE, "no HIP device: the HIP path has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(LVI_ERR_NO_DEVICE, "device index out of range");
+    if (p->batch_scans < 0 || p->batch_scans > LVI_MAX_BATCH) return fail(LVI_ERR_INVALID_ARG, "batch_scans must be 0..LVI_MAX_BATCH");
     lvi_lidar* h = new lvi_lidar();
+    h->slots.push_back(&h->d);
     h->d.P = *p; h->d.device = device;
+    const int S = std::max(p->batch_scans, 1);
+    if (S > 1) h->d.P.map_on_main_stream = 1;      // a batch fills the chip by itself; one stream keeps every slot's work in one order
     int32_t st = guarded(h, [&]() -> int32_t {
-        LVI_HIP(hipStreamCreateWithFlags(&h->d.ctx.stream, hipStreamNonBlocking));
-        LVI_HIP(hipStreamCreateWithFlags(&h->d.ctx2.stream, hipStreamNonBlocking));
-        LVI_HIP(hipEventCreateWithFlags(&h->d.evMain, hipEventDisableTiming));
-        LVI_HIP(hipEventCreateWithFlags(&h->d.evMap, hipEventDisableTiming));
-        h->d.ctx.prof = &h->d.prof; h->d.ctx2.prof = &h->d.prof;
-        lidar_allocate(h->d);
+        LidarDev& d = h->d;
+        LVI_HIP(hipStreamCreateWithFlags(&d.ctx.stream, hipStreamNonBlocking));
+        LVI_HIP(hipStreamCreateWithFlags(&d.ctx2.stream, hipStreamNonBlocking));
+        LVI_HIP(hipEventCreateWithFlags(&d.evMain, hipEventDisableTiming));
+        LVI_HIP(hipEventCreateWithFlags(&d.evMap, hipEventDisableTiming));
+        d.ctx.prof = &d.prof; d.ctx2.prof = &d.prof;
+        lidar_allocate(d);
+        for (int z = 1; z < S; z++) {
+            h->more.emplace_back(new LidarDev());
+            LidarDev& q = *h->more.back();
+            q.P = d.P; q.device = device; q.ctx = d.ctx; q.ctx2 = d.ctx2; q.map_owner = &d;
+            h->slots.push_back(&q);
+            lidar_allocate(q);
+        }
         return LVI_OK;
     });
     if (st != LVI_OK) { lvi_lidar_destroy(h); return st; }
@@ -201,34 +218,41 @@ int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** 
     return LVI_OK;
 }
 
+static void release_slot(LidarDev& d)
+{
+    d.voxRing.release(); d.voxScan.release(); d.voxMap.release(); d.voxGen.release();
+    d.arena.release();
+    if (d.h_icp) (void)hipHostFree(d.h_icp);
+    if (d.h_kfSeg) (void)hipHostFree(d.h_kfSeg);
+    for (int s = 0; s < 2; s++) {
+        if (d.h_raw[s]) (void)hipHostFree(d.h_raw[s]);
+        if (d.ev_raw[s]) (void)hipEventDestroy(d.ev_raw[s]);
+    }
+    if (d.graphExec) (void)hipGraphExecDestroy(d.graphExec);
+}
+
 void lvi_lidar_destroy(lvi_lidar* h)
 {
     if (!h) return;
-    (void)hipSetDevice(h->d.device);
-    if (h->d.ctx.stream) { (void)hipStreamSynchronize(h->d.ctx.stream); }
-    if (h->d.ctx2.stream) { (void)hipStreamSynchronize(h->d.ctx2.stream); }
-    h->d.prof.collect();
-    h->d.voxRing.release(); h->d.voxScan.release(); h->d.voxMap.release(); h->d.voxGen.release();
-    h->d.arena.release();
-    if (h->d.h_icp) (void)hipHostFree(h->d.h_icp);
-    if (h->d.h_kfSeg) (void)hipHostFree(h->d.h_kfSeg);
-    for (int s = 0; s < 2; s++) {
-        if (h->d.h_raw[s]) (void)hipHostFree(h->d.h_raw[s]);
-        if (h->d.ev_raw[s]) (void)hipEventDestroy(h->d.ev_raw[s]);
-    }
-    if (h->d.graphExec) (void)hipGraphExecDestroy(h->d.graphExec);
-    if (h->d.ctx.stream) (void)hipStreamDestroy(h->d.ctx.stream);
-    if (h->d.ctx2.stream) (void)hipStreamDestroy(h->d.ctx2.stream);
-    for (int s = 0; s < LVI_LIDAR_MARKS; s++) if (h->d.evMark[s]) (void)hipEventDestroy(h->d.evMark[s]);
-    if (h->d.evMain) (void)hipEventDestroy(h->d.evMain);
-    if (h->d.evMap) (void)hipEventDestroy(h->d.evMap);
+    LidarDev& d = h->d;
+    (void)hipSetDevice(d.device);
+    if (d.ctx.stream) { (void)hipStreamSynchronize(d.ctx.stream); }
+    if (d.ctx2.stream) { (void)hipStreamSynchronize(d.ctx2.stream); }
+    d.prof.collect();
+    for (auto& q : h->more) release_slot(*q);
+    release_slot(d);
+    if (d.ctx.stream) (void)hipStreamDestroy(d.ctx.stream);
+    if (d.ctx2.stream) (void)hipStreamDestroy(d.ctx2.stream);
+    for (int s = 0; s < LVI_LIDAR_MARKS; s++) if (d.evMark[s]) (void)hipEventDestroy(d.evMark[s]);
+    if (d.evMain) (void)hipEventDestroy(d.evMain);
+    if (d.evMap) (void)hipEventDestroy(d.evMap);
     delete h;
 }
 
 int32_t lvi_lidar_sync(lvi_lidar* h)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
-    return guarded(h, [&]() -> int32_t { sync(h->d); return LVI_OK; });
+    return guarded(h, [&]() -> int32_t { sync(h->cur()); return LVI_OK; });
 }
 
 int32_t lvi_lidar_mark(lvi_lidar* h, int32_t slot)
@@ -258,9 +282,9 @@ int32_t lvi_lidar_wait_mark(lvi_lidar* h, int32_t slot)
 int32_t lvi_scan_upload(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw)
 {
     if (!h || (n_raw > 0 && !pts)) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (n_raw > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    if (n_raw > h->cur().raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         d.n_raw = n_raw > 0 ? n_raw - 1 : 0;        // moveFromCustomMsg: i < point_num-1 (imageProjection.cpp:249)
         // the caller's (pageable) message is copied to pinned staging on the host and uploaded from there: the call
         // returns without a stream sync, and the runtime never has to pin / stage the user's memory itself
@@ -277,9 +301,9 @@ int32_t lvi_scan_upload(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw)
 int32_t lvi_scan_upload_device(lvi_lidar* h, const void* d_pts, int32_t n_raw)
 {
     if (!h || (n_raw > 0 && !d_pts)) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (n_raw > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    if (n_raw > h->cur().raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         d.n_raw = n_raw > 0 ? n_raw - 1 : 0;
         if (d.n_raw) LVI_HIP(hipMemcpyAsync(d.raw, d_pts, sizeof(lvi_livox_pt) * (size_t)d.n_raw, hipMemcpyDeviceToDevice, d.ctx.stream));
         LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
@@ -296,24 +320,24 @@ int32_t lvi_map_upload_device(lvi_lidar* h, const void* c, int32_t nc, const voi
         join_map(d);
         if (nc) LVI_HIP(hipMemcpyAsync(d.mapCornerRaw, c, sizeof(lvi_pt) * (size_t)nc, hipMemcpyDeviceToDevice, d.ctx.stream));
         if (ns) LVI_HIP(hipMemcpyAsync(d.mapSurfRaw, s, sizeof(lvi_pt) * (size_t)ns, hipMemcpyDeviceToDevice, d.ctx.stream));
-        d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.have_map = false;
+        d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.voxMap.bbox_cached = false; for (LidarDev* q : h->slots) q->have_map = false;
         return LVI_OK;
     });
 }
 int32_t lvi_scan_organize(lvi_lidar* h)
 {
-    if (!h || !h->d.have_raw) return fail(LVI_ERR_STATE, "no scan uploaded");
-    return guarded(h, [&]() -> int32_t { stage_organize(h->d); h->d.have_org = true; h->d.have_feat = h->d.have_ds = false; return LVI_OK; });
+    if (!h || !h->cur().have_raw) return fail(LVI_ERR_STATE, "no scan uploaded");
+    return guarded(h, [&]() -> int32_t { stage_organize(h->cur()); h->cur().have_org = true; h->cur().have_feat = h->cur().have_ds = false; return LVI_OK; });
 }
 int32_t lvi_scan_extract(lvi_lidar* h)
 {
-    if (!h || !h->d.have_org) return fail(LVI_ERR_STATE, "scan not organised");
-    return guarded(h, [&]() -> int32_t { stage_extract(h->d); h->d.have_feat = true; h->d.have_ds = false; return LVI_OK; });
+    if (!h || !h->cur().have_org) return fail(LVI_ERR_STATE, "scan not organised");
+    return guarded(h, [&]() -> int32_t { stage_extract(h->cur()); h->cur().have_feat = true; h->cur().have_ds = false; return LVI_OK; });
 }
 int32_t lvi_scan_downsample(lvi_lidar* h)
 {
-    if (!h || !h->d.have_feat) return fail(LVI_ERR_STATE, "features not extracted");
-    return guarded(h, [&]() -> int32_t { stage_downsample(h->d); h->d.have_ds = true; return LVI_OK; });
+    if (!h || !h->cur().have_feat) return fail(LVI_ERR_STATE, "features not extracted");
+    return guarded(h, [&]() -> int32_t { stage_downsample(h->cur()); h->cur().have_ds = true; return LVI_OK; });
 }
 int32_t lvi_map_upload(lvi_lidar* h, const lvi_pt* c, int32_t nc, const lvi_pt* s, int32_t ns)
 {
@@ -323,29 +347,30 @@ int32_t lvi_map_upload(lvi_lidar* h, const lvi_pt* c, int32_t nc, const lvi_pt* 
         LidarDev& d = h->d;
         h2d(d, d.mapCornerRaw, c, (size_t)nc); h2d(d, d.mapSurfRaw, s, (size_t)ns);
         sync(d);
-        d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.have_map = false;
+        d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.voxMap.bbox_cached = false; for (LidarDev* q : h->slots) q->have_map = false;
         return LVI_OK;
     });
 }
 int32_t lvi_map_build(lvi_lidar* h)
 {
     if (!h || !h->d.have_map_raw) return fail(LVI_ERR_STATE, "no map uploaded");
-    return guarded(h, [&]() -> int32_t { stage_map_build(h->d); h->d.have_map = true; return LVI_OK; });
+    // a batch handle re-voxelises and re-indexes the (shared) raw map for every slot, in one launch sequence
+    return guarded(h, [&]() -> int32_t { stage_map_build(Slots{h->slots.data(), (int)h->slots.size()}); return LVI_OK; });
 }
 
 int32_t lvi_scan_match_async(lvi_lidar* h, const float pose_init[6], void* d_record)
 {
     if (!h || !pose_init) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
-    return guarded(h, [&]() -> int32_t { set_pose_init(h->d, pose_init); stage_scan_match_enqueue(h->d, nullptr, d_record); h->have_icp_host = false; return LVI_OK; });
+    if (!h->cur().have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    return guarded(h, [&]() -> int32_t { set_pose_init(h->cur(), pose_init); stage_scan_match_enqueue(h->cur(), nullptr, d_record); h->have_icp_host = false; return LVI_OK; });
 }
 
 int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi_icp_result* out)
 {
     if (!h || !pose || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    if (!h->cur().have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         set_pose_init(d, pose);
         stage_scan_match_enqueue(d, imu, nullptr);
         int nq[3] = {0, 0, 0};
@@ -367,10 +392,11 @@ int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi
 int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, const float pose_init[6], void* d_record, int32_t rebuild_map)
 {
     if (!h || !pose_init || (n_raw > 0 && !d_pts)) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (n_raw > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    if (n_raw > h->cur().raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
     if (rebuild_map && !h->d.have_map_raw) return fail(LVI_ERR_STATE, "no map uploaded");
+    if (h->sel != 0) return fail(LVI_ERR_STATE, "lvi_scan_replay_enqueue runs on slot 0; batches go through lvi_scan_batch_run");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         join_map(d);
         // per-call inputs go in eagerly; the captured graph only reads fixed buffers of the handle
         d.n_raw = n_raw > 0 ? n_raw - 1 : 0;                     // moveFromCustomMsg drops the final point
@@ -412,13 +438,95 @@ int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, 
     });
 }
 
+// ---- batched form: S scans side by side in one launch sequence ------------------------------------
+static int32_t batch_check(lvi_lidar* h, int32_t n)
+{
+    if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
+    if (n < 1 || n > (int32_t)h->slots.size()) return fail(LVI_ERR_CAPACITY, "n_scans exceeds lvi_lidar_params.batch_scans");
+    return LVI_OK;
+}
+int32_t lvi_batch_select(lvi_lidar* h, int32_t slot)
+{
+    if (!h || slot < 0 || slot >= (int32_t)h->slots.size()) return fail(LVI_ERR_INVALID_ARG, "bad slot");
+    h->sel = slot;
+    return LVI_OK;
+}
+int32_t lvi_scan_batch_bind_device(lvi_lidar* h, int32_t n_scans, const void* const* d_pts, const int32_t* n_raw)
+{
+    int32_t st = batch_check(h, n_scans); if (st) return st;
+    if (!d_pts || !n_raw) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    for (int z = 0; z < n_scans; z++) {
+        if (n_raw[z] < 0 || (n_raw[z] > 0 && !d_pts[z])) return fail(LVI_ERR_INVALID_ARG, "bad scan");
+        if (n_raw[z] > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    }
+    for (int z = 0; z < n_scans; z++) {
+        LidarDev& q = *h->slots[z];
+        q.raw_bound = (const lvi_livox_pt*)d_pts[z];
+        q.n_raw = n_raw[z] > 0 ? n_raw[z] - 1 : 0;                  // moveFromCustomMsg drops the final point (imageProjection.cpp:249)
+        q.have_raw = true; q.have_org = q.have_feat = q.have_ds = false;
+    }
+    return LVI_OK;
+}
+int32_t lvi_scan_batch_upload(lvi_lidar* h, int32_t n_scans, const lvi_livox_pt* const* pts, const int32_t* n_raw)
+{
+    int32_t st = batch_check(h, n_scans); if (st) return st;
+    if (!pts || !n_raw) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    for (int z = 0; z < n_scans; z++) {
+        if (n_raw[z] < 0 || (n_raw[z] > 0 && !pts[z])) return fail(LVI_ERR_INVALID_ARG, "bad scan");
+        if (n_raw[z] > h->d.raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    }
+    return guarded(h, [&]() -> int32_t {
+        for (int z = 0; z < n_scans; z++) {
+            LidarDev& q = *h->slots[z];
+            q.raw_bound = nullptr;
+            q.n_raw = n_raw[z] > 0 ? n_raw[z] - 1 : 0;
+            const int slot = (q.raw_slot ^= 1);                      // pinned staging ring, as lvi_scan_upload
+            LVI_HIP(hipEventSynchronize(q.ev_raw[slot]));
+            std::memcpy(q.h_raw[slot], pts[z], sizeof(lvi_livox_pt) * (size_t)q.n_raw);
+            if (q.n_raw) LVI_HIP(hipMemcpyAsync(q.raw, q.h_raw[slot], sizeof(lvi_livox_pt) * (size_t)q.n_raw, hipMemcpyHostToDevice, q.ctx.stream));
+            LVI_HIP(hipEventRecord(q.ev_raw[slot], q.ctx.stream));
+            q.have_raw = true; q.have_org = q.have_feat = q.have_ds = false;
+        }
+        return LVI_OK;
+    });
+}
+int32_t lvi_scan_batch_run(lvi_lidar* h, int32_t n_scans, const float* pose_init, void* d_records, int32_t rebuild_map)
+{
+    int32_t st = batch_check(h, n_scans); if (st) return st;
+    if (!pose_init) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    for (int z = 0; z < n_scans; z++) if (!h->slots[z]->have_raw) return fail(LVI_ERR_STATE, "no scan bound / uploaded for a slot");
+    if (rebuild_map && !h->d.have_map_raw) return fail(LVI_ERR_STATE, "no map uploaded");
+    return guarded(h, [&]() -> int32_t {
+        const Slots sl{h->slots.data(), n_scans};
+        set_pose_init(sl, pose_init, true);
+        if (rebuild_map) stage_map_build(sl);
+        stage_organize(sl);
+        stage_extract(sl);
+        stage_downsample(sl);
+        for (int z = 0; z < n_scans; z++) { LidarDev& q = sl[z]; q.have_org = q.have_feat = q.have_ds = true; }
+        stage_scan_match_enqueue(sl, nullptr, d_records);
+        h->have_icp_host = false;
+        return LVI_OK;
+    });
+}
+int32_t lvi_scan_batch_get_records(lvi_lidar* h, int32_t n_scans, lvi_pose_record* out)
+{
+    int32_t st = batch_check(h, n_scans); if (st) return st;
+    if (!out) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    return guarded(h, [&]() -> int32_t {
+        for (int z = 0; z < n_scans; z++) d2h(h->d, out + z, &h->slots[z]->icp->record, 1);
+        sync(h->d);
+        return LVI_OK;                                               // device errors travel in each record's status
+    });
+}
+
 // ---- fetch ---------------------------------------------------------------------------------------
 int32_t lvi_get_scan_info(lvi_lidar* h, lvi_scan_info* out)
 {
     if (!h || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (!h->d.have_org) return fail(LVI_ERR_STATE, "scan not organised");
+    if (!h->cur().have_org) return fail(LVI_ERR_STATE, "scan not organised");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         const int n = read_int(d, d.d_n);
         out->n = n;
         if (out->capacity < n) return fail(LVI_ERR_CAPACITY, "scan_info capacity too small");
@@ -431,9 +539,9 @@ int32_t lvi_get_scan_info(lvi_lidar* h, lvi_scan_info* out)
 int32_t lvi_get_features(lvi_lidar* h, lvi_cloud* corner, lvi_cloud* surf)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (!h->d.have_feat) return fail(LVI_ERR_STATE, "features not extracted");
+    if (!h->cur().have_feat) return fail(LVI_ERR_STATE, "features not extracted");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         int32_t st = check_dev_status(d); if (st) return st;
         const Counts c = read_counts(d);
         st = fetch_cloud(d, d.corner, c.ncorner, corner); if (st) return st;
@@ -443,9 +551,9 @@ int32_t lvi_get_features(lvi_lidar* h, lvi_cloud* corner, lvi_cloud* surf)
 int32_t lvi_get_scan_ds(lvi_lidar* h, lvi_cloud* c0, lvi_cloud* c1)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    if (!h->cur().have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         const Counts c = read_counts(d);
         int32_t st = fetch_cloud(d, d.cornerDS, c.ncds, c0); if (st) return st;
         return fetch_cloud(d, d.surfDS, c.nsds, c1);
@@ -454,9 +562,9 @@ int32_t lvi_get_scan_ds(lvi_lidar* h, lvi_cloud* c0, lvi_cloud* c1)
 int32_t lvi_get_map_ds(lvi_lidar* h, lvi_cloud* c0, lvi_cloud* c1)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (!h->d.have_map) return fail(LVI_ERR_STATE, "map not built");
+    if (!h->cur().have_map) return fail(LVI_ERR_STATE, "map not built");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         int32_t st = check_dev_status(d); if (st) return st;
         const Counts c = read_counts(d);
         st = fetch_cloud(d, d.mapCornerDS, c.mcds, c0); if (st) return st;
@@ -467,7 +575,7 @@ int32_t lvi_get_counts(lvi_lidar* h, int32_t counts[8])
 {
     if (!h || !counts) return fail(LVI_ERR_INVALID_ARG, "null argument");
     return guarded(h, [&]() -> int32_t {
-        const Counts c = read_counts(h->d);
+        const Counts c = read_counts(h->cur());
         counts[0] = c.n; counts[1] = c.ncorner; counts[2] = c.nsurf; counts[3] = c.ncds; counts[4] = c.nsds; counts[5] = c.mcds; counts[6] = c.msds; counts[7] = 0;
         return LVI_OK;
     });
@@ -477,7 +585,7 @@ int32_t lvi_get_pose_record(lvi_lidar* h, lvi_pose_record* out)
 {
     if (!h || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         d2h(d, out, &d.icp->record, 1);
         sync(d);
         return check_dev_status(d);
@@ -518,14 +626,15 @@ int32_t lvi_keyframe_add(lvi_lidar* h, const lvi_pt* corner, int32_t nc, const l
 int32_t lvi_keyframe_add_current(lvi_lidar* h, const float pose[6], int32_t* index_out)
 {
     if (!h || !pose) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (!h->d.have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
+    if (!h->cur().have_ds) return fail(LVI_ERR_STATE, "scan not downsampled");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->d;                                          // the store
+        LidarDev& q = h->cur();                                      // the scan (selected batch slot)
         int nq[3] = {0, 0, 0};
-        d2h(d, nq, d.voxScan.d_nout, 3); sync(d);                    // a keyframe is saved every ~1 m of motion: one 12-byte read
+        d2h(q, nq, q.voxScan.d_nout, 3); sync(q);                    // a keyframe is saved every ~1 m of motion: one 12-byte read
         int32_t st = kf_reserve(h, nq[0], nq[1]); if (st) return st;
-        if (nq[0]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used, d.cornerDS, sizeof(lvi_pt) * (size_t)nq[0], hipMemcpyDeviceToDevice, d.ctx.stream));
-        if (nq[1]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used + nq[0], d.surfDS, sizeof(lvi_pt) * (size_t)nq[1], hipMemcpyDeviceToDevice, d.ctx.stream));
+        if (nq[0]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used, q.cornerDS, sizeof(lvi_pt) * (size_t)nq[0], hipMemcpyDeviceToDevice, d.ctx.stream));
+        if (nq[1]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used + nq[0], q.surfDS, sizeof(lvi_pt) * (size_t)nq[1], hipMemcpyDeviceToDevice, d.ctx.stream));
         return kf_commit(h, nq[0], nq[1], pose, index_out);
     });
 }
@@ -563,7 +672,11 @@ int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_key
         tc += h->d.kf_n_c[k]; ts += h->d.kf_n_s[k];
     }
     if (tc > h->d.map_cap || ts > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
-    return guarded(h, [&]() -> int32_t { stage_map_assemble(h->d, key_indices, n_keys); return LVI_OK; });
+    return guarded(h, [&]() -> int32_t {
+        stage_map_assemble(h->d, key_indices, n_keys);                                      // extractCloud's fuse loop into the raw map (slot 0)
+        stage_map_build(Slots{h->slots.data(), (int)h->slots.size()});                      // + the two VoxelGrids and the index, per slot
+        return LVI_OK;
+    });
 }
 
 int32_t lvi_map_update(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys)
@@ -574,12 +687,12 @@ int32_t lvi_map_update(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys)
 int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
-    h->d.dk_on = false;
+    h->cur().dk_on = false;
     if (!info || !info->imu_available) return LVI_OK;
     if (info->imu_pointer_cur < 1 || info->imu_pointer_cur >= LVI_DESKEW_MAX_IMU || !info->imu_time || !info->imu_rot_x || !info->imu_rot_y || !info->imu_rot_z)
         return fail(LVI_ERR_INVALID_ARG, "bad deskew table");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         const size_t m = (size_t)info->imu_pointer_cur + 1;
         const double* src[4] = {info->imu_time, info->imu_rot_x, info->imu_rot_y, info->imu_rot_z};
         for (int k = 0; k < 4; k++) h2d(d, d.d_dk + (size_t)k * LVI_DESKEW_MAX_IMU, src[k], m);
@@ -608,9 +721,9 @@ int32_t lvi_organize_scan(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw, 
 int32_t lvi_extract_features(lvi_lidar* h, const lvi_scan_info* in, lvi_cloud* corner, lvi_cloud* surf)
 {
     if (!h || !in) return fail(LVI_ERR_INVALID_ARG, "null argument");
-    if (in->n < 0 || in->n > h->d.ext_cap) return fail(LVI_ERR_CAPACITY, "scan_info.n exceeds capacity");
+    if (in->n < 0 || in->n > h->cur().ext_cap) return fail(LVI_ERR_CAPACITY, "scan_info.n exceeds capacity");
     int32_t st = guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         const int n = in->n, NS = d.P.N_SCAN;
         // ring bases: start_ring_index[r] = count_r + 4 (imageProjection.cpp:630)
         std::vector<int> base(NS + 1);
@@ -663,9 +776,9 @@ int32_t lvi_scan_to_map(lvi_lidar* h, const lvi_pt* corner, int32_t nc, const lv
                         const lvi_imu_hint* imu, float pose[6], lvi_icp_result* out)
 {
     if (!h || nc < 0 || ns < 0 || (nc > 0 && !corner) || (ns > 0 && !surf)) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
-    if (nc > h->d.ext_cap || ns > h->d.ext_cap) return fail(LVI_ERR_CAPACITY, "feature clouds exceed capacity");
+    if (nc > h->cur().ext_cap || ns > h->cur().ext_cap) return fail(LVI_ERR_CAPACITY, "feature clouds exceed capacity");
     int32_t st = guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         h2d(d, d.corner, corner, (size_t)nc); h2d(d, d.surf, surf, (size_t)ns);
         h2d(d, d.d_ncorner, &nc, 1); h2d(d, d.voxRing.d_nout + d.P.N_SCAN, &ns, 1);
         sync(d);
@@ -696,7 +809,7 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
 {
     if (!h) return fail(LVI_ERR_INVALID_ARG, "null handle");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         auto need_feat = [&]() { return d.have_feat && d.have_org; };
         switch (what) {
             case LVI_DBG_CURVATURE: {
@@ -723,9 +836,9 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
             case LVI_DBG_MAP_CORNER_RAW: case LVI_DBG_MAP_SURF_RAW: {
-                if (!d.have_map_raw) return fail(LVI_ERR_STATE, "no map");
+                if (!h->d.have_map_raw) return fail(LVI_ERR_STATE, "no map");
                 const bool sf = what == LVI_DBG_MAP_SURF_RAW;
-                const int n = sf ? d.n_map_surf : d.n_map_corner;
+                const int n = sf ? h->d.n_map_surf : h->d.n_map_corner;
                 std::vector<lvi_pt> v((size_t)n); d2h(d, v.data(), sf ? d.mapSurfRaw : d.mapCornerRaw, (size_t)n); sync(d);
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
@@ -760,9 +873,9 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
 int32_t lvi_debug_knn(lvi_lidar* h, int32_t which, const lvi_pt* queries, int32_t nq, int32_t* idx, float* sqd)
 {
     if (!h || !queries || !idx || !sqd || nq < 0 || which < 0 || which > 1) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
-    if (!h->d.have_map) return fail(LVI_ERR_STATE, "map not built");
+    if (!h->cur().have_map) return fail(LVI_ERR_STATE, "map not built");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         struct Scratch {                                   // freed on every way out, a throwing LVI_HIP included
             void* p[3] = {nullptr, nullptr, nullptr};
             ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
@@ -783,9 +896,9 @@ int32_t lvi_debug_knn(lvi_lidar* h, int32_t which, const lvi_pt* queries, int32_
 int32_t lvi_debug_residuals(lvi_lidar* h, int32_t which, const float pose[6], lvi_pt* coeff, uint8_t* flag, int32_t capacity, int32_t* n)
 {
     if (!h || !pose || !coeff || !flag || !n || which < 0 || which > 1) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
-    if (!h->d.have_map || !h->d.have_ds) return fail(LVI_ERR_STATE, "map or scan DS missing");
+    if (!h->cur().have_map || !h->cur().have_ds) return fail(LVI_ERR_STATE, "map or scan DS missing");
     return guarded(h, [&]() -> int32_t {
-        LidarDev& d = h->d;
+        LidarDev& d = h->cur();
         int nq[3];
         d2h(d, nq, d.voxScan.d_nout, 3); sync(d);
         *n = nq[which];

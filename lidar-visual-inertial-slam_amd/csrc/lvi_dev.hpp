@@ -96,6 +96,13 @@ struct ArenaSizer {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Batched launches: one launch sequence serves up to LVI_MAX_BATCH independent scans (SURVEY §7.3-6 i).  Every kernel
+// of the lidar path takes the argument blocks of all scans of the batch and picks its own by blockIdx.z, so a batch of S
+// scans costs the launches of one scan, and the one-workgroup kernels of the chain (scans, solves) run S workgroups wide.
+constexpr int MAX_BATCH = LVI_MAX_BATCH;
+template <class T> struct Batch { T a[MAX_BATCH]; };
+inline dim3 zdim(dim3 g, int S) { g.z = (unsigned)S; return g; }
+
 #ifdef __HIPCC__
 // ---------------------------------------------------------------------------
 // device side

@@ -71,8 +71,9 @@ __device__ int grid_meta_one(const GridArgs& a, int w)
     return 0;
 }
 
-__global__ void grid_meta_kernel(GridArgs a)
+__global__ void grid_meta_kernel(Batch<GridArgs> B_)
 {
+    const GridArgs& a = B_.a[blockIdx.z];
     __shared__ int err[2];
     if (threadIdx.x < 2) err[threadIdx.x] = grid_meta_one(a, threadIdx.x);
     __syncthreads();
@@ -103,8 +104,9 @@ __device__ __forceinline__ int cell_id_of(const GridIndex::Meta& m, const lvi_pt
 constexpr int GRID_PT_BLOCKS = 512;
 constexpr int GRID_SCAN_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void grid_count_kernel(GridArgs a)
+__global__ __launch_bounds__(256) void grid_count_kernel(Batch<GridArgs> B_)
 {
+    const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
     const GridIndex::Meta& m = *a.meta[w];
     if (!m.ok) return;
@@ -112,8 +114,9 @@ __global__ __launch_bounds__(256) void grid_count_kernel(GridArgs a)
 }
 
 // chunk b of the ncells + 1 entries: its total
-__global__ __launch_bounds__(256) void grid_scan_sum_kernel(GridArgs a)
+__global__ __launch_bounds__(256) void grid_scan_sum_kernel(Batch<GridArgs> B_)
 {
+    const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
     const GridIndex::Meta& m = *a.meta[w];
     const int total = m.ncells + 1;
@@ -128,8 +131,9 @@ __global__ __launch_bounds__(256) void grid_scan_sum_kernel(GridArgs a)
 }
 
 // cell_start[c] = points in cells < c, for c in [0, ncells]; cursor = the same; count back to zero
-__global__ __launch_bounds__(256) void grid_scan_apply_kernel(GridArgs a)
+__global__ __launch_bounds__(256) void grid_scan_apply_kernel(Batch<GridArgs> B_)
 {
+    const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
     const GridIndex::Meta& m = *a.meta[w];
     const int total = m.ncells + 1;
@@ -155,8 +159,9 @@ __global__ __launch_bounds__(256) void grid_scan_apply_kernel(GridArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void grid_scatter_kernel(GridArgs a)
+__global__ __launch_bounds__(256) void grid_scatter_kernel(Batch<GridArgs> B_)
 {
+    const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
     const GridIndex::Meta& m = *a.meta[w];
     if (!m.ok) return;
@@ -195,11 +200,18 @@ __device__ __forceinline__ void knn_insert(KnnKeys& r, unsigned long long key)
 // rows form one flat candidate list read in batches of KNN_KB (adjacent lanes read different rows, the index
 // is L2-resident).  Each lane keeps a private top-5; the G lists are merged by 5 rounds of a group-wide
 // (distance, index) minimum.  All G lanes end with the same result.
-constexpr int KNN_RPL = (25 + KNN_G - 1) / KNN_G;      // rows per lane
 
+// r2max: only neighbours with squared distance <= r2max can matter.  KNN_R2_FULL (the largest float below 1) is the
+// callers' own gate (sqDis[4] < 1.0); from the second Gauss-Newton iteration on the residual kernel passes the largest
+// squared distance from the query's NEW position to its five PREVIOUS neighbours: five map points lie inside that ball, so
+// the true fifth-nearest distance cannot exceed it and the scan shrinks from the unit ball to a ~0.4 m one (exact: every
+// cell the smaller ball reaches is still scanned, ties included since the test is <=).
+constexpr float KNN_R2_FULL = 0x1.fffffep-1f;
+template <int G, int KNN_KB>
 __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
-                                                  float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr)
+                                                  float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr, float r2max = KNN_R2_FULL)
 {
+    constexpr int KNN_RPL = (25 + G - 1) / G;         // rows per lane
 #define LVI_KT(slot) do { if (tk) tk[slot] = clock64(); } while (0)
     LVI_KT(0);
     KnnKeys r;
@@ -207,7 +219,8 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
     for (int k = 0; k < 5; k++) r.k[k] = KNN_EMPTY;
     if (m.ok && m.n > 0) {
         const float e = (float)m.edge, inv_e = (float)m.inv_edge;
-        const int R = m.R, W = 2 * R + 1, nrows = W * W;
+        // a neighbour within sqrt(r2max) <= edge is at most one cell away on every axis (0.5 m cells: r2max < 0.24)
+        const int R = (m.R == 2 && r2max < 0.24f) ? 1 : m.R, W = 2 * R + 1, nrows = W * W;
         // cell of the query (double, as cell_of) and its position inside that cell in [0,1) (f32 is plenty: the row
         // tests below only have to be conservative, and they carry a 1e-4 margin)
         const double gx = ((double)qx - m.origin[0]) * m.inv_edge, gy = ((double)qy - m.origin[1]) * m.inv_edge, gz = ((double)qz - m.origin[2]) * m.inv_edge;
@@ -220,16 +233,17 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         st[0] = 0;
 #pragma unroll
         for (int t = 0; t < KNN_RPL; t++) {
-            const int rr = sub + KNN_G * t;
+            const int rr = sub + G * t;
             int rb = 0, len = 0;
-            const int dy = rr % W - R, dz = rr / W - R;
+            const int rq = W == 3 ? rr / 3 : rr / 5;                   // W is 3 or 5: constant divisors
+            const int dy = rr - rq * W - R, dz = rq - R;
             const int y = cy + dy, z = cz + dz;
             if (rr < nrows && y >= 0 && y < m.dim[1] && z >= 0 && z < m.dim[2]) {
                 // distance (m) from the query to the row's slab along y and z; 0 inside
                 const float ddy = dy == 0 ? 0.f : (dy > 0 ? (float)dy - ty : ty - (float)(dy + 1)) * e;
                 const float ddz = dz == 0 ? 0.f : (dz > 0 ? (float)dz - tz : tz - (float)(dz + 1)) * e;
                 // margins: the f32 distance of a candidate may round below 1 when the exact one is just above
-                const float rem = 1.0f + 1e-4f - ddy * ddy - ddz * ddz;
+                const float rem = r2max + 1e-4f - ddy * ddy - ddz * ddz;
                 if (rem > 0.f) {
                     const float sx = sqrtf(rem) * inv_e + 1e-4f;
                     const int x0 = max(cx + (int)floorf(tx - sx), 0), x1 = min(cx + (int)floorf(tx + sx), m.dim[0] - 1);
@@ -246,7 +260,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         for (int t = 0; t < KNN_RPL; t++) { const int len = st[t + 1]; st[t + 1] = st[t] + len; off[t] -= st[t]; }
         const int T = st[KNN_RPL];
         LVI_KT(1);
-        constexpr int KNN_KB = 8;
+        if (tk) tk[5] = T;
         for (int f0 = 0; f0 < T; f0 += KNN_KB) {
             lvi_pt p[KNN_KB];
 #pragma unroll
@@ -264,18 +278,19 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
                 // Only neighbours closer than 1 m can matter: the callers reject a feature unless its 5th neighbour has
                 // sqDis < 1.0, and if five such neighbours exist they ARE the five nearest.
-                const bool take = f0 + u < T && dist < 1.0f;
+                const bool take = f0 + u < T && dist <= r2max;
                 knn_insert(r, take ? knn_key(dist, __float_as_int(p[u].intensity)) : KNN_EMPTY);
             }
         }
     }
+    if (tk) tk[4] = 0;
     LVI_KT(3);
     // merge: 5 rounds of a group-wide minimum; the owner of the winner pops it (keys are unique per lane)
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         unsigned long long h = r.k[0];
 #pragma unroll
-        for (int o = KNN_G / 2; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(h, o, 64); h = v < h ? v : h; }
+        for (int o = G / 2; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(h, o, 64); h = v < h ? v : h; }
         out.d[k] = __uint_as_float((unsigned)(h >> 32)); out.i[k] = (int)(unsigned)h;
         if (r.k[0] == h && h != KNN_EMPTY) { r.k[0] = r.k[1]; r.k[1] = r.k[2]; r.k[2] = r.k[3]; r.k[3] = r.k[4]; r.k[4] = KNN_EMPTY; }
     }
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256) void knn_debug_kernel(const GridIndex::Meta* m
     const int t = blockIdx.x * (256 / KNN_G) + threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
     if (t >= nq) return;
     Knn5 r;
-    knn5_search_group(*meta, cell_start, sorted, q[t].x, q[t].y, q[t].z, sub, r);
+    knn5_search_group<KNN_G, 8>(*meta, cell_start, sorted, q[t].x, q[t].y, q[t].z, sub, r);
     if (sub != 0) return;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -434,6 +449,9 @@ struct IcpArgs {
     void* d_record;
     long long* cyc;
     const int* d_status;                          // [2] device error words: scan side, map build
+    const float* pose_init;                       // [6] initial guess (device)
+    int have_map;
+    int* nn_prev;                                 // [Q][5] neighbours of the previous iteration (-1: fewer than five within 1 m)
 };
 
 __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
@@ -530,8 +548,10 @@ static_assert(ICP_QPB <= 64, "the residual phase runs on one wavefront");
 //      27 products in f64, into LDS; then 28 threads add the 32 rows in fixed order → one partial per workgroup.
 // (Doing B inside the 8-lane groups made every wavefront execute the whole eigen/QR code for 8 active lanes;
 // the kernel is VALU-issue bound, ~2500 instructions per lane, not latency bound: half-filled wavefronts in B cost.)
-__global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
+template <int G, int KB>
+__global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
 {
+    const IcpArgs& a = B_.a[blockIdx.z];
     if (a.st->done) return;
     const int nC = a.nq[0], nS = a.nq[1];
     if (blockIdx.x * ICP_QPB >= nC + nS) return;
@@ -545,7 +565,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
     if (threadIdx.x < 6) sT[threadIdx.x] = a.st->pose.trig[threadIdx.x];
     __syncthreads();
     {
-        const int ql = threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
+        const int ql = threadIdx.x / G, sub = threadIdx.x % G;
         const int t = blockIdx.x * ICP_QPB + ql;
         const bool active = t < nC + nS;
         const bool isC = t < nC;
@@ -555,11 +575,34 @@ __global__ __launch_bounds__(ICP_BLOCK) void icp_residual_kernel(IcpArgs a)
         const int w = (active && !isC) ? 1 : 0;
         LVI_STAMP(0);
         Knn5 r;
-        long long tk[4] = {0, 0, 0, 0};
-        if (active) knn5_search_group(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr);
+        long long tk[6] = {0, 0, 0, 0, 0, 0};
+        // from the second iteration on: bound the search by the previous neighbours' distances under the new pose
+        float r2 = KNN_R2_FULL;
+        if (active && a.nn_prev && a.st->iters > 0) {
+            const int* __restrict__ pn = a.nn_prev + (size_t)t * 5;
+            const int i0 = pn[0];
+            if (i0 >= 0) {
+                const lvi_pt* __restrict__ map = a.mapds[w];
+                float b = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const lvi_pt p = map[j == 0 ? i0 : pn[j]];
+                    const float ex = sub_rn(sel.x, p.x), ey = sub_rn(sel.y, p.y), ez = sub_rn(sel.z, p.z);
+                    b = fmaxf(b, add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez)));
+                }
+                if (b < 1.0f) r2 = b;
+            }
+        }
+        if (active) knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2);
         if (active && sub == 0) snn[ql] = r;
+        if (active && sub == 0 && a.nn_prev) {
+            int* __restrict__ pn = a.nn_prev + (size_t)t * 5;
+            const bool five = r.d[4] < 1.0f;
+#pragma unroll
+            for (int j = 0; j < 5; j++) pn[j] = five ? r.i[j] : -1;
+        }
         LVI_STAMP(1);
-        if (stamp) { cyc[6] = tk[1] - tk[0]; cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; }
+        if (stamp) { cyc[6] = tk[1] - tk[0]; cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; a.cyc[13] = tk[5]; a.cyc[14] = r2 < KNN_R2_FULL ? 1 : 0; }
     }
     __syncthreads();
     if (threadIdx.x < ICP_QPB) {
@@ -624,13 +667,20 @@ __device__ void make_pose(IcpPose& p)
     p.trig[4] = F; p.trig[5] = E;
 }
 
-__global__ void set_pose_init_kernel(float* dst, float t0, float t1, float t2, float t3, float t4, float t5)
+struct PoseInitArgs { float* dst; float t[6]; int* d_status; };
+__global__ void set_pose_init_kernel(Batch<PoseInitArgs> B_)
 {
-    dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3; dst[4] = t4; dst[5] = t5;
+    const PoseInitArgs& a = B_.a[blockIdx.z];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.dst[k] = a.t[k];
+    if (a.d_status) a.d_status[0] = 0;            // scan-side device status word of a batch slot (single scans: cleared by the upload)
 }
 
-__global__ void icp_init_kernel(IcpArgs a, const float* __restrict__ pose_init, int have_map)
+__global__ void icp_init_kernel(Batch<IcpArgs> B_)
 {
+    const IcpArgs& a = B_.a[blockIdx.z];
+    const float* __restrict__ pose_init = a.pose_init;
+    const int have_map = a.have_map;
     IcpState& s = *a.st;
     for (int k = 0; k < 6; k++) s.pose.T[k] = pose_init[k];
     make_pose(s.pose);
@@ -860,13 +910,14 @@ __device__ void q_to_rpy(const Quatd& q, double& roll, double& pitch, double& ya
 }
 
 // the last iteration's solve launch also finishes the scan (one launch less on the critical path)
-__global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(IcpArgs a, int iter, int last)
+__global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(Batch<IcpArgs> B_, int iter, int last)
 {
+    const IcpArgs& a = B_.a[blockIdx.z];
     icp_solve_body(a, iter);                    // threads other than 0 come back early
     if (last && threadIdx.x == 0) icp_finish_body(a);
 }
 
-__global__ void icp_finish_kernel(IcpArgs a) { icp_finish_body(a); }       // only launched when icp_max_iters == 0
+__global__ void icp_finish_kernel(Batch<IcpArgs> B_) { icp_finish_body(B_.a[blockIdx.z]); }       // only launched when icp_max_iters == 0
 
 __device__ void icp_finish_body(const IcpArgs& a)
 {
@@ -929,7 +980,7 @@ __global__ __launch_bounds__(ICP_BLOCK) void residual_debug_kernel(IcpArgs a, in
     if (active) ori = a.q[which][t];
     const lvi_pt sel = to_map(pose->A, ori);
     Knn5 r;
-    if (active) knn5_search_group(*a.meta[which], a.cell_start[which], a.sorted[which], sel.x, sel.y, sel.z, sub, r);
+    if (active) knn5_search_group<KNN_G, 8>(*a.meta[which], a.cell_start[which], a.sorted[which], sel.x, sel.y, sel.z, sub, r);
     if (active && sub == 0) {
         lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
         const bool ok = which == 0 ? corner_residual(a, sel, r, cf) : surf_residual(a, ori, sel, r, cf);
@@ -951,7 +1002,7 @@ IcpArgs icp_args(LidarDev& d)
     a.q[0] = d.cornerDS; a.q[1] = d.surfDS; a.nq = d.voxScan.d_nout;
     for (int w = 0; w < 2; w++) { a.meta[w] = d.grid[w].meta; a.cell_start[w] = d.grid[w].cell_start; a.sorted[w] = d.grid[w].sorted; }
     a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
-    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles; a.d_status = d.d_status;
+    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles; a.d_status = d.d_status; a.nn_prev = d.knn_bound ? d.nnPrev : nullptr;
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;
@@ -965,24 +1016,8 @@ void join_map(LidarDev& d)
     if (d.map_pending) { LVI_HIP(hipStreamWaitEvent(d.ctx.stream, d.evMap, 0)); d.map_pending = false; }
 }
 
-// The map build does not depend on the current scan, so it runs on its own stream and overlaps the
-// scan-side stages (organise / sector kernel / scan voxel grids, which occupy only a few CUs); the
-// main stream joins it right before scan matching.
-void stage_map_build(LidarDev& d)
+static GridArgs grid_args(LidarDev& d)
 {
-    const Ctx& cx = d.P.map_on_main_stream ? d.ctx : d.ctx2;
-    // everything already enqueued on the main stream (map upload, the previous scan's GN loop reading the
-    // previous index) must finish before the map buffers are rewritten
-    const bool forked = cx.stream != d.ctx.stream;
-    if (forked) {
-        LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));
-        LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
-    }
-    // raw map counts are host-known here; the voxel plan wants them in device memory
-    d.voxMap.n_host[0] = d.n_map_corner; d.voxMap.n_host[1] = d.n_map_surf; d.voxMap.use_n_host = true;       // instead of a 1-thread launch writing d_dyn
-    const double n = (double)d.n_map_corner + (double)d.n_map_surf;
-    voxel_downsample_batch(cx, d.voxMap, "map", n);
-
     GridArgs g{};
     for (int w = 0; w < 2; w++) {
         g.meta[w] = d.grid[w].meta; g.cell_start[w] = d.grid[w].cell_start; g.sorted[w] = d.grid[w].sorted;
@@ -991,17 +1026,59 @@ void stage_map_build(LidarDev& d)
     g.vox = d.voxMap.d_grid; g.nout = d.voxMap.d_nout;
     g.ds[0] = d.mapCornerDS; g.ds[1] = d.mapSurfDS;
     g.cap = d.map_cap; g.max_cells = d.max_cells; g.d_status = d.d_status;
+    return g;
+}
+
+// The map build does not depend on the current scan, so it runs on its own stream and overlaps the
+// scan-side stages (organise / sector kernel / scan voxel grids, which occupy only a few CUs); the
+// main stream joins it right before scan matching.  Batch: every slot re-voxelises and re-indexes the (shared) raw map
+// into its own DS map and index, as the reference does for every scan.
+void stage_map_build(const Slots& sl)
+{
+    LidarDev& d = sl.first();
+    const Ctx& cx = d.P.map_on_main_stream ? d.ctx : d.ctx2;
+    // everything already enqueued on the main stream (map upload, the previous scan's GN loop reading the
+    // previous index) must finish before the map buffers are rewritten
+    const bool forked = cx.stream != d.ctx.stream;
+    if (forked) {
+        LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));
+        LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
+    }
+    // bbox of the raw map: one pass when the map was (re)written, not one per re-voxelisation (PCL's getMinMax3D is a pure
+    // function of the unchanged input)
+    if (!d.voxMap.bbox_cached) {
+        d.voxMap.n_host[0] = d.n_map_corner; d.voxMap.n_host[1] = d.n_map_surf; d.voxMap.use_n_host = true;
+        voxel_bbox_pass(cx, d.voxMap, "map", (double)d.n_map_corner + (double)d.n_map_surf);
+        d.voxMap.bbox_cached = true;
+    }
+    // raw map counts are host-known here; the voxel plan wants them in device memory
+    const VoxelPlan* plans[MAX_BATCH];
+    Batch<GridArgs> G;
+    for (int z = 0; z < sl.n; z++) {
+        LidarDev& q = sl[z];
+        q.n_map_corner = d.n_map_corner; q.n_map_surf = d.n_map_surf;
+        q.voxMap.n_host[0] = d.n_map_corner; q.voxMap.n_host[1] = d.n_map_surf; q.voxMap.use_n_host = true;       // instead of a 1-thread launch writing d_dyn
+        q.voxMap.bbox_cached = true;
+        plans[z] = &q.voxMap;
+        G.a[z] = grid_args(q);
+        q.have_map = true;
+    }
+    for (int z = sl.n; z < MAX_BATCH; z++) G.a[z] = G.a[0];
+    const double n = ((double)d.n_map_corner + (double)d.n_map_surf) * sl.n;
+    voxel_downsample_batch(cx, plans, sl.n, "map", n);
     const double nds = 0.02 * n;     // nominal DS size for byte accounting only
-    LVI_LAUNCH(cx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1), dim3(64), 0, cx.stream, g));
-    LVI_LAUNCH(cx, "grid_count", 16.0 * nds, hipLaunchKernelGGL(grid_count_kernel, dim3(GRID_PT_BLOCKS, 2), dim3(256), 0, cx.stream, g));
-    LVI_LAUNCH(cx, "grid_scan_sum", 0, hipLaunchKernelGGL(grid_scan_sum_kernel, dim3(GRID_SCAN_BLOCKS, 2), dim3(256), 0, cx.stream, g));
-    LVI_LAUNCH(cx, "grid_scan_apply", 0, hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GRID_SCAN_BLOCKS, 2), dim3(256), 0, cx.stream, g));
-    LVI_LAUNCH(cx, "grid_scatter", 32.0 * nds, hipLaunchKernelGGL(grid_scatter_kernel, dim3(GRID_PT_BLOCKS, 2), dim3(256), 0, cx.stream, g));
+    const unsigned S = (unsigned)sl.n;
+    LVI_LAUNCH(cx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1, 1, S), dim3(64), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_count", 16.0 * nds, hipLaunchKernelGGL(grid_count_kernel, dim3(GRID_PT_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_scan_sum", 0, hipLaunchKernelGGL(grid_scan_sum_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_scan_apply", 0, hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_scatter", 32.0 * nds, hipLaunchKernelGGL(grid_scatter_kernel, dim3(GRID_PT_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
     if (forked) {
         LVI_HIP(hipEventRecord(d.evMap, cx.stream));
         d.map_pending = true;
     }
 }
+void stage_map_build(LidarDev& d) { stage_map_build(OneSlot(d).s); }
 
 // f-4.  extractCloud's fuse loop (mapOptimization.cpp:931-957): every listed keyframe cloud through
 // transformPointCloud (:347-366) with the key's pose, written at its place in laserCloud{Corner,Surf}FromMap.
@@ -1046,34 +1123,62 @@ void stage_map_assemble(LidarDev& d, const int32_t* keys, int n_keys)
                                                                                      d.d_kfSeg, d.kfPool, d.mapCornerRaw, d.mapSurfRaw));
     }
     d.n_map_corner = oc; d.n_map_surf = os; d.have_map_raw = true;
-    stage_map_build(d);
-    d.have_map = true;
+    d.voxMap.bbox_cached = false;
 }
 
-void set_pose_init(LidarDev& d, const float p[6])
+void set_pose_init(const Slots& sl, const float* p, bool clear_status)
 {
-    hipLaunchKernelGGL(set_pose_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, d.d_pose_init, p[0], p[1], p[2], p[3], p[4], p[5]);
+    Batch<PoseInitArgs> B;
+    for (int z = 0; z < sl.n; z++) {
+        B.a[z].dst = sl[z].d_pose_init;
+        for (int k = 0; k < 6; k++) B.a[z].t[k] = p[6 * z + k];
+        B.a[z].d_status = clear_status ? sl[z].d_status : nullptr;
+    }
+    for (int z = sl.n; z < MAX_BATCH; z++) B.a[z] = B.a[0];
+    const Ctx& cx = sl.first().ctx;
+    hipLaunchKernelGGL(set_pose_init_kernel, dim3(1, 1, sl.n), dim3(1), 0, cx.stream, B);
     LVI_HIP(hipGetLastError());
 }
+void set_pose_init(LidarDev& d, const float p[6]) { set_pose_init(OneSlot(d).s, p, false); }
 
-void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record)
+void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_records)
 {
+    LidarDev& d = sl.first();
     join_map(d);
-    IcpArgs a = icp_args(d);
-    a.imu_available = imu ? imu->imu_available : 0;
-    a.imu_roll = imu ? imu->imu_roll_init : 0.f;
-    a.imu_pitch = imu ? imu->imu_pitch_init : 0.f;
-    a.d_record = d_record;
-    const double Q = 0.25 * d.n_raw;       // nominal query count for byte accounting only
-    LVI_LAUNCH(d.ctx, "icp_init", 0, hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a, d.d_pose_init, d.have_map ? 1 : 0));
+    Batch<IcpArgs> B;
+    double Q = 0;
+    for (int z = 0; z < sl.n; z++) {
+        IcpArgs a = icp_args(sl[z]);
+        a.imu_available = imu ? imu->imu_available : 0;
+        a.imu_roll = imu ? imu->imu_roll_init : 0.f;
+        a.imu_pitch = imu ? imu->imu_pitch_init : 0.f;
+        a.d_record = d_records ? (void*)((char*)d_records + sizeof(lvi_pose_record) * (size_t)z) : nullptr;
+        a.pose_init = sl[z].d_pose_init;
+        a.have_map = sl[z].have_map ? 1 : 0;
+        B.a[z] = a;
+        Q += 0.25 * sl[z].n_raw;           // nominal query count for byte accounting only
+    }
+    for (int z = sl.n; z < MAX_BATCH; z++) B.a[z] = B.a[0];
+    const IcpArgs& a = B.a[0];
+    const unsigned S = (unsigned)sl.n;
+    const Ctx& cx = d.ctx;
+    LVI_LAUNCH(cx, "icp_init", 0, hipLaunchKernelGGL(icp_init_kernel, dim3(1, 1, S), dim3(1), 0, cx.stream, B));
     for (int it = 0; it < a.max_iters; it++) {
         // (the grid covers ext_cap features; the ~1 200 workgroups beyond the actual count exit at once — measured: launching
         // exactly the occupied 360 instead changes nothing)
-        LVI_LAUNCH(d.ctx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL(icp_residual_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a));
-        LVI_LAUNCH(d.ctx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(SOLVE_THREADS), 0, d.ctx.stream, a, it, it == a.max_iters - 1 ? 1 : 0));
+        // iteration 0 searches the unit ball with 8 lanes per feature; later iterations search the (much smaller) ball of the
+        // previous neighbours, where the per-lane fixed cost dominates: fewer lanes per feature (d.icp_g1)
+        const int G1 = it == 0 ? 8 : d.icp_g1;
+        const dim3 rg(d.nblk_icp, 1, S);
+        if (G1 == 8) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<8, 8>), rg, dim3(512), 0, cx.stream, B));
+        else if (G1 == 4) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<4, 4>), rg, dim3(256), 0, cx.stream, B));
+        else if (G1 == 2) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<2, 4>), rg, dim3(128), 0, cx.stream, B));
+        else LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<8, 4>), rg, dim3(512), 0, cx.stream, B));
+        LVI_LAUNCH(cx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1, 1, S), dim3(SOLVE_THREADS), 0, cx.stream, B, it, it == a.max_iters - 1 ? 1 : 0));
     }
-    if (a.max_iters <= 0) LVI_LAUNCH(d.ctx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1), dim3(1), 0, d.ctx.stream, a));
+    if (a.max_iters <= 0) LVI_LAUNCH(cx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1, 1, S), dim3(1), 0, cx.stream, B));
 }
+void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record) { stage_scan_match_enqueue(OneSlot(d).s, imu, d_record); }
 
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd)
 {

@@ -104,6 +104,9 @@ struct LidarDev {
     IcpState* icp = nullptr;
     double* icpPartial = nullptr;                          // [nblk_icp][28]
     lvi_pt* coeff = nullptr; uint8_t* flag = nullptr;      // [ext_cap] corner queries first, then surf
+    int* nnPrev = nullptr;                                 // [ext_cap][5] neighbours found by the previous GN iteration
+    int icp_g1 = 4;                                        // lanes per feature in GN iterations >= 1 (LVI_ICP_G1 = 8 | 4 | 2 | 84 (8 lanes, batches of 4))
+    bool knn_bound = true;                                 // LVI_KNN_NO_BOUND=1 at create: every iteration searches the whole unit ball (tests: same bits)
     int nblk_icp = 0;
     IcpState* h_icp = nullptr;                             // pinned host mirror
     float* d_pose_init = nullptr;                          // [6] initial guess of the next scan match (device)
@@ -113,11 +116,29 @@ struct LidarDev {
     // stage flags (host)
     bool have_raw = false, have_org = false, have_feat = false, have_ds = false, have_map_raw = false, have_map = false;
     bool gen_valid = false; int gen_n = 0;
+    // batch slots (lvi_lidar_params.batch_scans > 1): slot z > 0 shares slot 0's streams, profiler, keyframe store and RAW
+    // local map (the replay configuration: one frozen raw map, re-voxelised and re-indexed for every scan)
+    LidarDev* map_owner = nullptr;                         // slot 0 for z > 0
+    const lvi_livox_pt* raw_bound = nullptr;               // lvi_scan_batch_bind_device: the scan is read in place (no copy)
 };
+
+// the scans of one batched launch sequence: slot 0 owns the streams, the profiler and the raw local map
+struct Slots {
+    LidarDev* const* p; int n;
+    LidarDev& operator[](int i) const { return *p[i]; }
+    LidarDev& first() const { return *p[0]; }
+};
+struct OneSlot { LidarDev* one; Slots s; explicit OneSlot(LidarDev& d) : one(&d), s{&one, 1} {} };
 
 // lvi_scan.hip
 void lidar_allocate(LidarDev& d);
-void stage_map_assemble(LidarDev& d, const int32_t* keys, int n_keys);      // f-4: fuse the keyframes into the raw map buffers, then stage_map_build
+void stage_organize(const Slots& s);
+void stage_extract(const Slots& s);
+void stage_downsample(const Slots& s);
+void stage_map_build(const Slots& s);
+void stage_scan_match_enqueue(const Slots& s, const lvi_imu_hint* imu, void* d_records);   // slot z writes its record to d_records + 32 z (when not null)
+void set_pose_init(const Slots& s, const float* pose_init, bool clear_status);          // [n][6]; clear_status: also zero the scan-side device status words
+void stage_map_assemble(LidarDev& d, const int32_t* keys, int n_keys);      // f-4: fuse the keyframes into the raw map buffers (the caller builds)
 void stage_organize(LidarDev& d);
 void stage_extract(LidarDev& d);
 void stage_downsample(LidarDev& d);

@@ -4,6 +4,8 @@
 //   sectors    FeatureExtraction::extractFeatures greedy selection   (featureExtraction.cpp:158-237)
 //   per-ring / per-scan VoxelGrid                                     (:239-243, mapOptimization.cpp:987-999)
 // All counts stay in device memory; the host only enqueues.
+#include <cstdlib>
+
 #include "lvi_lidar.hpp"
 
 namespace lvi {
@@ -82,8 +84,9 @@ __device__ __forceinline__ int org_classify(const OrgArgs& a, const lvi_livox_pt
     return row;
 }
 
-__global__ __launch_bounds__(256) void org_count_kernel(OrgArgs a)
+__global__ __launch_bounds__(256) void org_count_kernel(Batch<OrgArgs> B_)
 {
+    const OrgArgs& a = B_.a[blockIdx.z];
     __shared__ int cnt[MAX_N_SCAN];
     if (threadIdx.x < MAX_N_SCAN) cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -115,8 +118,9 @@ __global__ __launch_bounds__(256) void org_count_kernel(OrgArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void org_scan_kernel(OrgArgs a)
+__global__ __launch_bounds__(256) void org_scan_kernel(Batch<OrgArgs> B_)
 {
+    const OrgArgs& a = B_.a[blockIdx.z];
     __shared__ int ws[8];
     __shared__ int total[MAX_N_SCAN];
     const int nt = (a.n_raw + ORG_TILE - 1) / ORG_TILE;
@@ -165,8 +169,9 @@ __global__ __launch_bounds__(256) void org_scan_kernel(OrgArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void org_scatter_kernel(OrgArgs a)
+__global__ __launch_bounds__(256) void org_scatter_kernel(Batch<OrgArgs> B_)
 {
+    const OrgArgs& a = B_.a[blockIdx.z];
     constexpr int NW = 4;
     __shared__ int waveCnt[NW][MAX_N_SCAN];
     if (threadIdx.x < NW * MAX_N_SCAN) (&waveCnt[0][0])[threadIdx.x] = 0;
@@ -261,8 +266,9 @@ __device__ __forceinline__ bool occl_B(const float* r, const int* col, int i)   
     return abs(col[i + 1] - col[i]) < 10 && !((double)sub_rn(r[i], r[i + 1]) > 0.3) && (double)sub_rn(r[i + 1], r[i]) > 0.3;
 }
 
-__global__ __launch_bounds__(256) void feat_smooth_kernel(FeatArgs a)
+__global__ __launch_bounds__(256) void feat_smooth_kernel(Batch<FeatArgs> B_)
 {
+    const FeatArgs& a = B_.a[blockIdx.z];
     const int n = *a.d_n;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0) for (int q = threadIdx.x; q < a.N_SCAN * 12; q += 256) a.spill[q] = 0u;
@@ -320,8 +326,9 @@ __device__ __forceinline__ uint64_t bits_from(const uint64_t* words, int pos)
     return sh ? ((lo >> sh) | (words[wi + 1] << (64 - sh))) : lo;
 }
 
-__global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
+__global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArgs> B_)
 {
+    const FeatArgs& a = B_.a[blockIdx.z];
     __shared__ float s_curv[FEAT_SEG_CAP + 32];
     __shared__ uint8_t s_pick[FEAT_SEG_CAP + 16], s_reach[FEAT_SEG_CAP + 16];
     __shared__ int8_t s_label[FEAT_SEG_CAP + 16];
@@ -650,8 +657,9 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(FeatArgs a)
 }
 
 // corners in output order (ring, sector, pick order) + segment descriptors of the per-ring VoxelGrid
-__global__ void feat_finalize_kernel(FeatArgs a)
+__global__ void feat_finalize_kernel(Batch<FeatArgs> B_)
 {
+    const FeatArgs& a = B_.a[blockIdx.z];
     __shared__ int off[MAX_N_SCAN * 6 + 1];
     const int ns = a.N_SCAN * 6;
     if (threadIdx.x == 0) {
@@ -705,10 +713,12 @@ void layout(AR& ar, LidarDev& d)
     d.voxRing.allocate(ar, NS, d.ring_cap, true);
     d.cornerDS = ar.template alloc<lvi_pt>(d.ext_cap); d.surfDS = ar.template alloc<lvi_pt>(d.ext_cap);
     d.voxScan.allocate(ar, 2, d.ext_cap, false);
-    d.mapCornerRaw = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfRaw = ar.template alloc<lvi_pt>(d.map_cap);
+    if (d.map_owner) { d.mapCornerRaw = d.map_owner->mapCornerRaw; d.mapSurfRaw = d.map_owner->mapSurfRaw; }
+    else { d.mapCornerRaw = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfRaw = ar.template alloc<lvi_pt>(d.map_cap); }
     d.mapCornerDS = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfDS = ar.template alloc<lvi_pt>(d.map_cap);
     d.voxMap.allocate(ar, 2, d.map_cap, false);
     d.voxMap.centroid_lanes = 32;
+    if (d.map_owner) d.voxMap.d_mmPartial = d.map_owner->voxMap.d_mmPartial;      // bbox partials of the shared raw map
     for (int w = 0; w < 2; w++) {
         d.grid[w].cell_start = ar.template alloc<int>((size_t)d.max_cells + 2);
         d.grid[w].count = ar.template alloc<int>((size_t)d.max_cells + 2);
@@ -717,7 +727,7 @@ void layout(AR& ar, LidarDev& d)
         d.grid[w].sorted = ar.template alloc<lvi_pt>(d.map_cap);
         d.grid[w].meta = ar.template alloc<GridIndex::Meta>(1);
     }
-    const int gen_cap = std::max(d.raw_cap, d.map_cap);
+    const int gen_cap = d.map_owner ? 64 : std::max(d.raw_cap, d.map_cap);      // one-call voxel / transform entry points run on slot 0
     d.genIn = ar.template alloc<lvi_pt>(gen_cap); d.genOut = ar.template alloc<lvi_pt>(gen_cap);
     d.voxGen.allocate(ar, 1, gen_cap, false);
     d.genKeysDbg = ar.template alloc<unsigned>(gen_cap);
@@ -727,6 +737,7 @@ void layout(AR& ar, LidarDev& d)
     d.d_pose_init = ar.template alloc<float>(8);
     d.icpPartial = ar.template alloc<double>((size_t)d.nblk_icp * 28);
     d.coeff = ar.template alloc<lvi_pt>(d.ext_cap); d.flag = ar.template alloc<uint8_t>(d.ext_cap);
+    d.nnPrev = ar.template alloc<int>((size_t)d.ext_cap * 5);
 }
 
 FeatArgs feat_args(LidarDev& d)
@@ -754,11 +765,14 @@ void lidar_allocate(LidarDev& d)
     d.ext_cap = (int)std::max<long long>(std::min<long long>(d.raw_cap, full), 64);
     d.map_cap = std::max(d.P.max_map_points, 64);
     d.nblk_org = div_up(d.raw_cap, ORG_TILE);
-    d.kf_pool_cap = d.P.max_keyframes > 0 ? std::max(d.P.max_keyframe_points, 0) : 0;
+    d.kf_pool_cap = (d.P.max_keyframes > 0 && !d.map_owner) ? std::max(d.P.max_keyframe_points, 0) : 0;
     d.kf_seg_cap = 2 * std::max(d.P.max_keyframes, 0) + 2048;       // an assembly may list a key more than once
     // cells of the KNN grid (0.5 m, or the next multiple that fits): sized from the map capacity — three int arrays per grid
     // and map, 400 MB at 2^24 — so that small handles stay small; a map whose extent needs more gets coarser cells (still exact)
     d.max_cells = (int)std::min<long long>(1ll << 24, std::max<long long>(1ll << 18, 4ll * d.map_cap));
+    { const char* e = getenv("LVI_KNN_NO_BOUND"); d.knn_bound = !(e && e[0] == '1'); }
+    { const char* e = getenv("LVI_VB_BINS"); if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && b <= VB_NB) { d.voxMap.bin_pts = a; d.voxMap.bin_max = b; } } }
+    { const char* e = getenv("LVI_ICP_G1"); if (e) d.icp_g1 = atoi(e); if (!d.knn_bound) d.icp_g1 = 8; }
     d.feat_handover_ticks = d.P.sector_handover_wait_us < 0 ? 0 : 100ll * (d.P.sector_handover_wait_us > 0 ? d.P.sector_handover_wait_us : 2000);
     d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / KNN_G);
     ArenaSizer sz;
@@ -792,31 +806,50 @@ void lidar_allocate(LidarDev& d)
     LVI_HIP(hipStreamSynchronize(d.ctx.stream));
 }
 
-void stage_organize(LidarDev& d)
+static OrgArgs org_args(LidarDev& d)
 {
-    OrgArgs a{d.raw, d.n_raw, d.blockCnt, d.nblk_org, d.ringBase, d.startR, d.endR, d.d_n, d.pts, d.range, d.col,
-              d.P.N_SCAN, d.P.Horizon_SCAN, d.P.downsampleRate, d.P.lidarMinRange, d.P.lidarMaxRange, d.d_status,
-              d.dk_on ? 1 : 0, d.dk_cur, d.dk_t0, d.d_dk, d.d_dk_first, d.d_dk_startInv};
-    const int nb = std::max(1, div_up(d.n_raw, ORG_TILE));
-    const double n = d.n_raw;
-    LVI_LAUNCH(d.ctx, "org_count", 20.0 * n, hipLaunchKernelGGL(org_count_kernel, dim3(nb), dim3(256), 0, d.ctx.stream, a));
-    LVI_LAUNCH(d.ctx, "org_scan", 0, hipLaunchKernelGGL(org_scan_kernel, dim3(1), dim3(256), 0, d.ctx.stream, a));
-    LVI_LAUNCH(d.ctx, "org_scatter", 20.0 * n + 24.0 * n, hipLaunchKernelGGL(org_scatter_kernel, dim3(nb), dim3(256), 0, d.ctx.stream, a));
+    return OrgArgs{d.raw_bound ? d.raw_bound : d.raw, d.n_raw, d.blockCnt, d.nblk_org, d.ringBase, d.startR, d.endR, d.d_n, d.pts, d.range, d.col,
+                   d.P.N_SCAN, d.P.Horizon_SCAN, d.P.downsampleRate, d.P.lidarMinRange, d.P.lidarMaxRange, d.d_status,
+                   d.dk_on ? 1 : 0, d.dk_cur, d.dk_t0, d.d_dk, d.d_dk_first, d.d_dk_startInv};
 }
 
-void stage_extract(LidarDev& d)
+void stage_organize(const Slots& sl)
 {
-    FeatArgs a = feat_args(d);
-    const double n = d.n_raw;
-    LVI_LAUNCH(d.ctx, "feat_smooth", 8.0 * n + 8.0 * n, hipLaunchKernelGGL(feat_smooth_kernel, dim3(div_up(d.ext_cap, 256)), dim3(256), 0, d.ctx.stream, a));
-    LVI_LAUNCH(d.ctx, "feat_sector", 8.0 * n, hipLaunchKernelGGL(feat_sector_kernel, dim3(d.P.N_SCAN * 6), dim3(FEAT_THREADS), 0, d.ctx.stream, a));
-    LVI_LAUNCH(d.ctx, "feat_finalize", 0, hipLaunchKernelGGL(feat_finalize_kernel, dim3(1), dim3(256), 0, d.ctx.stream, a));
-    voxel_downsample_batch(d.ctx, d.voxRing, "ring", n);
+    Batch<OrgArgs> B;
+    int nb = 1; double n = 0;
+    for (int z = 0; z < sl.n; z++) { B.a[z] = org_args(sl[z]); nb = std::max(nb, div_up(sl[z].n_raw, ORG_TILE)); n += sl[z].n_raw; }
+    for (int z = sl.n; z < MAX_BATCH; z++) B.a[z] = B.a[0];
+    const Ctx& cx = sl.first().ctx;
+    LVI_LAUNCH(cx, "org_count", 20.0 * n, hipLaunchKernelGGL(org_count_kernel, dim3(nb, 1, sl.n), dim3(256), 0, cx.stream, B));
+    LVI_LAUNCH(cx, "org_scan", 0, hipLaunchKernelGGL(org_scan_kernel, dim3(1, 1, sl.n), dim3(256), 0, cx.stream, B));
+    LVI_LAUNCH(cx, "org_scatter", 20.0 * n + 24.0 * n, hipLaunchKernelGGL(org_scatter_kernel, dim3(nb, 1, sl.n), dim3(256), 0, cx.stream, B));
 }
 
-void stage_downsample(LidarDev& d)
+void stage_extract(const Slots& sl)
 {
-    voxel_downsample_batch(d.ctx, d.voxScan, "scan", 0.4 * d.n_raw);
+    Batch<FeatArgs> B;
+    const VoxelPlan* plans[MAX_BATCH];
+    double n = 0;
+    for (int z = 0; z < sl.n; z++) { B.a[z] = feat_args(sl[z]); plans[z] = &sl[z].voxRing; n += sl[z].n_raw; }
+    for (int z = sl.n; z < MAX_BATCH; z++) B.a[z] = B.a[0];
+    LidarDev& d = sl.first();
+    const Ctx& cx = d.ctx;
+    LVI_LAUNCH(cx, "feat_smooth", 8.0 * n + 8.0 * n, hipLaunchKernelGGL(feat_smooth_kernel, dim3(div_up(d.ext_cap, 256), 1, sl.n), dim3(256), 0, cx.stream, B));
+    LVI_LAUNCH(cx, "feat_sector", 8.0 * n, hipLaunchKernelGGL(feat_sector_kernel, dim3(d.P.N_SCAN * 6, 1, sl.n), dim3(FEAT_THREADS), 0, cx.stream, B));
+    LVI_LAUNCH(cx, "feat_finalize", 0, hipLaunchKernelGGL(feat_finalize_kernel, dim3(1, 1, sl.n), dim3(256), 0, cx.stream, B));
+    voxel_downsample_batch(cx, plans, sl.n, "ring", n);
 }
+
+void stage_downsample(const Slots& sl)
+{
+    const VoxelPlan* plans[MAX_BATCH];
+    double n = 0;
+    for (int z = 0; z < sl.n; z++) { plans[z] = &sl[z].voxScan; n += 0.4 * sl[z].n_raw; }
+    voxel_downsample_batch(sl.first().ctx, plans, sl.n, "scan", n);
+}
+
+void stage_organize(LidarDev& d) { stage_organize(OneSlot(d).s); }
+void stage_extract(LidarDev& d) { stage_extract(OneSlot(d).s); }
+void stage_downsample(LidarDev& d) { stage_downsample(OneSlot(d).s); }
 
 }  // namespace lvi

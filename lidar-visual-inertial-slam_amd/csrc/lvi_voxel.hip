@@ -36,6 +36,7 @@ struct VoxArgs {
     unsigned long long* chunkTabV; unsigned* chunkTabC; int max_multi;   // [nseg][max_multi] LDS tables of the chunks of multi-chunk bins
     int n_host[4]; int use_n_host;                     // host-known segment lengths (raw map), else dyn[].n
     const int* n_dev[4];                               // producer's device counters (scan grids), else dyn[].n
+    int bin_pts, bin_max;                              // binned path: aim at bin_pts points per bin, at most bin_max bins
 };
 
 __device__ __forceinline__ int seg_len(const VoxArgs& a, int s)
@@ -44,8 +45,9 @@ __device__ __forceinline__ int seg_len(const VoxArgs& a, int s)
     return n < 0 ? 0 : (n > a.seg_cap ? a.seg_cap : n);
 }
 
-__global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vox_minmax_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const int n = seg_len(a, s);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.d_n[s] = n;          // read by every later kernel of the batch
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(VoxArgs a)
 
 // grid geometry of one segment from its bbox (g.bb, g.n_valid already set): PCL's overflow rule, min_b / div_b /
 // divb_mul, key width.  Shared by the multi-workgroup and the single-workgroup paths.
-__device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap, float ilo, float ihi)
+__device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap, float ilo, float ihi, int bin_pts, int bin_max)
 {
     g.overflow = 0; g.nvox = 0; g.out_off = 0;
     g.ncells = 0ull; g.nbins = 0; g.bin_shift = VB_CL_LOG; g.fx_k = 0; g.fx_ki = 0;
@@ -152,7 +154,7 @@ __device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap, float ilo, f
     // about a thousand bins for a dense map (fewer for a few thousand points): few enough that a tile of consecutive points touches few of them (one global reservation
     // per tile and bin), many enough to fill the chip; never more than VB_NB, and beyond 1024 voxels per bin (sparse
     // grids) a bin is swept once per occupied 1024-voxel sub-range
-    const unsigned long long target = (unsigned long long)max(64, min(g.n_valid / 2048, 1024));
+    const unsigned long long target = (unsigned long long)max(64, min(g.n_valid / bin_pts, bin_max));
     int sh = 6;
     while (sh < VB_CL_LOG && (ncells >> sh) > target) sh++;
     while (((ncells + (1ull << sh) - 1ull) >> sh) > (unsigned long long)VB_NB) sh++;
@@ -168,10 +170,12 @@ __device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap, float ilo, f
 }
 
 
-__global__ __launch_bounds__(64) void vox_setup_kernel(VoxArgs a)
+__global__ __launch_bounds__(64) void vox_setup_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.x;                     // one wavefront per segment
     VoxGrid& g = a.grid[s];
+    if (threadIdx.x == 0) a.d_n[s] = seg_len(a, s);                  // (also written by vox_minmax; a batch with a cached bbox skips that pass)
     {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         float ilo = INFINITY, ihi = -INFINITY;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(64) void vox_setup_kernel(VoxArgs a)
             g.bb[0] = g.bb[1] = g.bb[2] = 0xFFFFFFFFu; g.bb[3] = g.bb[4] = g.bb[5] = 0u;
             ilo = ihi = 0.f;
         }
-        vox_setup_math(g, a.st[s].leaf, a.seg_cap, ilo, ihi);
+        vox_setup_math(g, a.st[s].leaf, a.seg_cap, ilo, ihi, a.bin_pts, a.bin_max);
     }
     a.d_nbits[s] = g.nbits;
     if (a.h_ncells) a.h_ncells[s] = g.ncells;                        // pinned host: AUTO's hint for the next batch
@@ -225,8 +229,9 @@ __device__ __forceinline__ unsigned vox_key_of(const VoxGrid& g, const lvi_pt* i
     return (unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2;
 }
 
-__global__ __launch_bounds__(256) void vox_keys_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vox_keys_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const int n = a.d_n[s];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -253,8 +258,9 @@ __device__ __forceinline__ bool is_head(const unsigned* keys, int i, unsigned se
     return k != sentinel && (i == 0 || keys[i - 1] != k);
 }
 
-__global__ __launch_bounds__(256) void vox_heads_count_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vox_heads_count_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const int n = a.d_n[s];
     const int base = blockIdx.x * VOX_HT;
@@ -270,8 +276,9 @@ __global__ __launch_bounds__(256) void vox_heads_count_kernel(VoxArgs a)
     if (threadIdx.x == 0) a.blockHeads[s * a.nblk_h + blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(256) void vox_heads_scan_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vox_heads_scan_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     __shared__ int ws[8];
     for (int s = 0; s < a.nseg; s++) {
         const int n = a.d_n[s];
@@ -300,8 +307,9 @@ __global__ __launch_bounds__(256) void vox_heads_scan_kernel(VoxArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void vox_heads_assign_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vox_heads_assign_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const int n = a.d_n[s];
     const int base = blockIdx.x * VOX_HT;
@@ -348,8 +356,9 @@ __device__ __forceinline__ lvi_pt fx_centroid(const VoxGrid& g, unsigned long lo
 // SORTED path centroid (pcl::CentroidPoint over the voxel's points).  VOX_CG (8, or 32 for the dense local map)
 // lanes share a voxel: lane i sums points i, i+G, … of the voxel, then the partial sums are added up.
 template <int VOX_CG>
-__global__ __launch_bounds__(256) void vox_centroid_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vox_centroid_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const VoxGrid& g = a.grid[s];
     const int sub = threadIdx.x % VOX_CG;
@@ -406,8 +415,9 @@ __device__ __forceinline__ WaveRun wave_runs(unsigned v)
     return r;
 }
 
-__global__ __launch_bounds__(256) void vb_hist_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_hist_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const int n = a.d_n[s];
     const VoxGrid& g = a.grid[s];
@@ -433,8 +443,9 @@ __global__ __launch_bounds__(256) void vb_hist_kernel(VoxArgs a)
 }
 
 // per segment: binStart = exclusive scan of binCount, cursor = binStart, binCount back to zero
-__global__ __launch_bounds__(256) void vb_scan_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.x;
     const int nbins = a.grid[s].nbins;
     unsigned* gc = a.binCount + (size_t)s * VB_NB * VB_PAD;
@@ -470,8 +481,9 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(VoxArgs a)
     if (threadIdx.x == 0) { bs[nbins] = tot; cs[nbins] = ctot; ms[nbins] = mtot; }
 }
 
-__global__ __launch_bounds__(256) void vb_scatter_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_scatter_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const int n = a.d_n[s];
     const int base = blockIdx.x * VB_STILE;
@@ -573,8 +585,9 @@ __device__ __forceinline__ int vb_emit(const VbCells& L, const VoxGrid& g, lvi_p
 // One workgroup per chunk of <= VB_CH bucketed points of one bin.  A bin that is a single chunk is finished here;
 // the chunks of a larger bin leave their LDS tables in chunkTab and vb_merge adds them up (no global atomics,
 // so a bin with 10^5 points is spread over 25 workgroups instead of keeping one busy for 0.2 ms).
-__global__ __launch_bounds__(256) void vb_accum_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_accum_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const VoxGrid& g = a.grid[s];
     const int nbins = g.nbins, sh = g.bin_shift;
@@ -636,8 +649,9 @@ __global__ __launch_bounds__(256) void vb_accum_kernel(VoxArgs a)
 }
 
 // bins of more than one chunk: add the chunk tables up and emit
-__global__ __launch_bounds__(256) void vb_merge_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_merge_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const VoxGrid& g = a.grid[s];
     const int nbins = g.nbins, sh = g.bin_shift;
@@ -671,8 +685,9 @@ __global__ __launch_bounds__(256) void vb_merge_kernel(VoxArgs a)
 }
 
 // binOut = exclusive scan of binVox per segment; voxel counts and output offsets of the batch
-__global__ __launch_bounds__(256) void vb_outscan_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_outscan_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     __shared__ int ws[8];
     constexpr int PER = VB_NB / 256;
     for (int s = 0; s < a.nseg; s++) {
@@ -701,8 +716,9 @@ __global__ __launch_bounds__(256) void vb_outscan_kernel(VoxArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void vb_copy_kernel(VoxArgs a)
+__global__ __launch_bounds__(256) void vb_copy_kernel(Batch<VoxArgs> B_)
 {
+    const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
     const VoxGrid& g = a.grid[s];
     lvi_pt* __restrict__ out = (a.concat ? a.st[0].out : a.st[s].out) + g.out_off;
@@ -754,7 +770,7 @@ static VoxArgs make_args(const VoxelPlan& p)
                    p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
                    p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
                    {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0,
-                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}};
+                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max};
 }
 
 void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs)
@@ -803,12 +819,23 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
         for (int v = 0; v < g.nvox; v++) { cells[v] = (int32_t)sk[st[v]]; counts[v] = st[v + 1] - st[v]; }
     }
     // per-point keys: recompute into keysA (scratch is free once the outputs are written)
-    const VoxArgs a = make_args(p);
-    hipLaunchKernelGGL(vox_keys_kernel, dim3(div_up(n_in, 256), 1), dim3(256), 0, ctx.stream, a);
+    Batch<VoxArgs> B;
+    B.a[0] = make_args(p);
+    hipLaunchKernelGGL(vox_keys_kernel, dim3(div_up(n_in, 256), 1), dim3(256), 0, ctx.stream, B);
     LVI_HIP(hipGetLastError());
     keys.resize(n_in);
     LVI_HIP(hipMemcpyAsync(keys.data(), p.sort.keysA, sizeof(unsigned) * n_in, hipMemcpyDeviceToHost, ctx.stream));
     LVI_HIP(hipStreamSynchronize(ctx.stream));
+}
+
+void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
+{
+    Batch<VoxArgs> B;
+    B.a[0] = make_args(p);
+    for (int z = 1; z < MAX_BATCH; z++) B.a[z] = B.a[0];
+    char nm[48];
+    snprintf(nm, sizeof(nm), "vox_minmax/%s", tag);
+    LVI_LAUNCH(ctx, nm, 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, 1), dim3(256), 0, ctx.stream, B));
 }
 
 int voxel_resolve_mode(const VoxelPlan& p)
@@ -826,40 +853,67 @@ int voxel_resolve_mode(const VoxelPlan& p)
 
 void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
 {
-    const VoxArgs a = make_args(p);
-    const int mode = voxel_resolve_mode(p);
-    p.last_mode = mode;
+    const VoxelPlan* one = &p;
+    voxel_downsample_batch(ctx, &one, 1, tag, n_hint);
+}
+
+// S plans of identical shape (the same plan of S batch slots), one launch sequence: blockIdx.z = slot
+void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S, const char* tag, double n_hint)
+{
+    const VoxelPlan& p = *plans[0];
+    // the realisation must be the same for the whole launch: sorted as soon as one slot asks for it
+    int mode = VOX_BINNED;
+    for (int z = 0; z < S; z++) if (voxel_resolve_mode(*plans[z]) == VOX_SORTED) mode = VOX_SORTED;
+    if (mode == VOX_SORTED && S > 1) {
+        // the radix sort is not batched over slots (sparse outdoor grids only): slot by slot
+        for (int z = 0; z < S; z++) {
+            const int keep = plans[z]->mode;
+            const_cast<VoxelPlan*>(plans[z])->mode = VOX_SORTED;
+            voxel_downsample_batch(ctx, plans + z, 1, tag, n_hint / S);
+            const_cast<VoxelPlan*>(plans[z])->mode = keep;
+        }
+        return;
+    }
+    Batch<VoxArgs> B;
+    for (int z = 0; z < S; z++) { B.a[z] = make_args(*plans[z]); plans[z]->last_mode = mode; }
+    for (int z = S; z < MAX_BATCH; z++) B.a[z] = B.a[0];
+    const VoxArgs& a = B.a[0];
     char nm[16][48];
     const char* base[16] = {"vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid",
                             "vb_hist", "vb_scan", "vb_scatter", "vb_accum", "vb_outscan", "vb_copy", "vb_merge", "", ""};
     for (int i = 0; i < 14; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
-    LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg), dim3(256), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg), dim3(64), 0, ctx.stream, a));
+    // the bbox pass is skipped when every plan of the batch holds the partial records of its (unchanged) input: the raw
+    // local map gets them where its points are touched anyway — upload / assembly — instead of once per re-voxelisation
+    bool cached = true;
+    for (int z = 0; z < S; z++) cached = cached && plans[z]->bbox_cached;
+    if (!cached) LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, S), dim3(256), 0, ctx.stream, B));
+    LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, S), dim3(64), 0, ctx.stream, B));
     if (mode == VOX_BINNED) {
-        const dim3 gt(div_up(p.seg_cap, VB_STILE), p.nseg);
-        const dim3 gb(std::max(64, std::min(div_up(p.seg_cap, 2048), VB_ACC_BLOCKS)), p.nseg);       // grid-stride over the bins
-        const dim3 gh2(std::min(div_up(p.seg_cap, VB_TILE), 512), p.nseg);
-        LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, a));
-        LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg), dim3(256), 0, ctx.stream, a));
-        LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, a));
-        const dim3 ga(std::max(256, std::min(2 * div_up(p.seg_cap, VB_CH), 2048)), p.nseg);      // grid-stride over the chunks
-        LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel, ga, dim3(256), 0, ctx.stream, a));
-        LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, gb, dim3(256), 0, ctx.stream, a));
-        LVI_LAUNCH(ctx, nm[11], 0, hipLaunchKernelGGL(vb_outscan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
-        LVI_LAUNCH(ctx, nm[12], 0, hipLaunchKernelGGL(vb_copy_kernel, gb, dim3(256), 0, ctx.stream, a));
+        const dim3 gt(div_up(p.seg_cap, VB_STILE), p.nseg, S);
+        const dim3 gb(std::max(64, std::min(div_up(p.seg_cap, 2048), VB_ACC_BLOCKS)), p.nseg, S);       // grid-stride over the bins
+        const dim3 gh2(std::min(div_up(p.seg_cap, VB_TILE), 512), p.nseg, S);
+        LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg, 1, S), dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, B));
+        const dim3 ga(std::max(256, std::min(2 * div_up(p.seg_cap, VB_CH), 2048)), p.nseg, S);      // grid-stride over the chunks
+        LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel, ga, dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, gb, dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[11], 0, hipLaunchKernelGGL(vb_outscan_kernel, dim3(1, 1, S), dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[12], 0, hipLaunchKernelGGL(vb_copy_kernel, gb, dim3(256), 0, ctx.stream, B));
         return;
     }
+    (void)a;
     const dim3 gp(div_up(p.seg_cap, 256), p.nseg), gh(p.nblk_h, p.nseg);
-    LVI_LAUNCH(ctx, nm[2], 24.0 * n_hint, hipLaunchKernelGGL(vox_keys_kernel, gp, dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[2], 24.0 * n_hint, hipLaunchKernelGGL(vox_keys_kernel, gp, dim3(256), 0, ctx.stream, B));
     radix_sort_pairs(ctx, p.sort, p.d_n, p.d_nbits, 4, tag, n_hint);
-    LVI_LAUNCH(ctx, nm[3], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_count_kernel, gh, dim3(256), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[4], 0, hipLaunchKernelGGL(vox_heads_scan_kernel, dim3(1), dim3(256), 0, ctx.stream, a));
-    LVI_LAUNCH(ctx, nm[5], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_assign_kernel, gh, dim3(256), 0, ctx.stream, a));
+    LVI_LAUNCH(ctx, nm[3], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_count_kernel, gh, dim3(256), 0, ctx.stream, B));
+    LVI_LAUNCH(ctx, nm[4], 0, hipLaunchKernelGGL(vox_heads_scan_kernel, dim3(1), dim3(256), 0, ctx.stream, B));
+    LVI_LAUNCH(ctx, nm[5], 4.0 * n_hint, hipLaunchKernelGGL(vox_heads_assign_kernel, gh, dim3(256), 0, ctx.stream, B));
     const dim3 gc(std::max(1, std::min(div_up(p.seg_cap, 256 / 8), 8192)), p.nseg);
     if (p.centroid_lanes >= 32)
-        LVI_LAUNCH(ctx, nm[6], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<32>, gc, dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[6], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<32>, gc, dim3(256), 0, ctx.stream, B));
     else
-        LVI_LAUNCH(ctx, nm[6], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<8>, gc, dim3(256), 0, ctx.stream, a));
+        LVI_LAUNCH(ctx, nm[6], 20.0 * n_hint, hipLaunchKernelGGL(vox_centroid_kernel<8>, gc, dim3(256), 0, ctx.stream, B));
 }
 
 }  // namespace lvi

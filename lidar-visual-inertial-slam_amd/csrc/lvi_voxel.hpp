@@ -81,6 +81,8 @@ struct VoxelPlan {
     int max_multi = 0;
     unsigned long long* h_ncells = nullptr;   // pinned host, [nseg]: div_b product of the latest run (AUTO's hint)
     mutable int last_mode = VOX_SORTED;       // what the latest voxel_downsample_batch enqueued
+    int bin_pts = 2048, bin_max = 1024;       // binned path: points aimed at per bin, most bins (<= VB_NB)
+    bool bbox_cached = false;                 // d_mmPartial holds the bbox partials of the CURRENT input (voxel_bbox_pass ran after the input was written)
 
     template <class AR> void allocate(AR& ar, int nseg_, int seg_cap_, bool concat)
     {
@@ -127,6 +129,11 @@ struct VoxelPlan {
 // 16.8 M cells (four sweeps per bin), SORTED for sparser ones.  d_dyn must have been written (on the same
 // stream) by the producer.  n_hint: nominal total input points, for byte accounting only.
 void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan& plan, const char* tag, double n_hint);
+// the same plan of S batch slots (identical shapes) in ONE launch sequence, blockIdx.z = slot; n_hint = points of all slots
+void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S, const char* tag, double n_hint);
+// the bbox partial records of the plan's current input, as a pass of its own (sets nothing on the plan: the caller owns
+// bbox_cached and clears it whenever the input changes)
+void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& plan, const char* tag, double n_hint);
 // the realisation the next voxel_downsample_batch of this plan will enqueue (AUTO resolved from the previous batch's hint)
 int voxel_resolve_mode(const VoxelPlan& plan);
 

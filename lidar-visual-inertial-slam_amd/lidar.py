@@ -221,6 +221,31 @@ class LidarHotpath:
         st = self.lib.check(self.lib.dll.lvi_scan_match(self._h, C.byref(hint) if hint else None, pose_c, C.byref(res)), "lvi_scan_match")
         return self._result_dict(st, res, pose_c)
 
+    # ---- batched form (lvi_scan_batch_*) -------------------------------------------
+    def batch_bind_device(self, d_ptrs, n_raws):
+        n = len(d_ptrs)
+        arr = (C.c_void_p * n)(*[int(p) for p in d_ptrs]); nr = (C.c_int32 * n)(*[int(v) for v in n_raws])
+        self.lib.check(self.lib.dll.lvi_scan_batch_bind_device(self._h, n, arr, nr), "lvi_scan_batch_bind_device")
+
+    def batch_upload(self, scans):
+        keep = [np.ascontiguousarray(s, dtype=A.LIVOX_DTYPE) for s in scans]
+        n = len(keep)
+        arr = (C.c_void_p * n)(*[k.ctypes.data for k in keep]); nr = (C.c_int32 * n)(*[len(k) for k in keep])
+        self.lib.check(self.lib.dll.lvi_scan_batch_upload(self._h, n, arr, nr), "lvi_scan_batch_upload")
+
+    def batch_run(self, poses, d_records_ptr=0, rebuild_map=True):
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
+        self.lib.check(self.lib.dll.lvi_scan_batch_run(self._h, len(p), p.ctypes.data_as(C.POINTER(C.c_float)),
+                                                       C.c_void_p(int(d_records_ptr)) if d_records_ptr else None, 1 if rebuild_map else 0), "lvi_scan_batch_run")
+
+    def batch_get_records(self, n):
+        rec = np.zeros((int(n), 8), np.float32)
+        self.lib.check(self.lib.dll.lvi_scan_batch_get_records(self._h, int(n), A._ptr(rec)), "lvi_scan_batch_get_records")
+        return rec
+
+    def batch_select(self, slot):
+        self.lib.check(self.lib.dll.lvi_batch_select(self._h, int(slot)), "lvi_batch_select")
+
     def scan_match_async(self, pose, d_record_ptr):
         pose_c = (C.c_float * 6)(*[float(v) for v in pose])
         self.lib.check(self.lib.dll.lvi_scan_match_async(self._h, pose_c, C.c_void_p(int(d_record_ptr))), "lvi_scan_match_async")

@@ -64,3 +64,60 @@ def replay_scans(handle, scans, guesses, rank=0, world=1, dist=None, device="cpu
             if j < n:
                 out[j] = g[rk, 0]
     return out
+
+
+class RollingReplay:
+    """The replay loop bench.py times, factored out so that the CPU tier can run it (gloo, oracle-backed handles).
+
+    B handles per rank, each fed `depth` steps ahead: before handle b receives its scans of step i the host waits for
+    the mark b recorded after step i - depth (lvi_lidar_wait_mark), so no queue runs dry while the host prepares the
+    neighbours' scans, and never more than `depth` steps are in flight per handle.  After all handles got step i, the
+    records of step i - depth are final on every handle and are gathered across ranks (`gather(j)`: RCCL / gloo
+    all_gather of the step's 32-byte pose records; a no-op for one rank).  `issue(i, b, handle)` enqueues whatever a
+    step means for one handle — one scan, or a batch of S scans in one launch sequence — without synchronising.
+    depth 0 = synchronise every handle after every step (the non-rolling form).
+    """
+
+    def __init__(self, handles, issue, gather=None, depth=2):
+        self.handles, self.issue, self.gather = list(handles), issue, gather
+        self.depth = max(0, min(int(depth), 8))             # LVI_LIDAR_MARKS
+        self.pending = []                                   # steps whose records have not been gathered yet
+        self.gathered = []                                  # steps gathered, in order (tests read this)
+
+    def step(self, i):
+        for b, h in enumerate(self.handles):
+            if self.depth:
+                h.wait_mark(i % self.depth)
+            self.issue(i, b, h)
+            if self.depth:
+                h.mark(i % self.depth)
+        if not self.depth:
+            for h in self.handles:
+                h.sync()
+            self._gather(i)
+            return
+        self.pending.append(i)
+        if len(self.pending) > self.depth:
+            self._gather(self.pending.pop(0))
+
+    def flush(self):
+        """finish everything in flight and gather what is left (inside the timed region)"""
+        for h in self.handles:
+            h.sync()
+        while self.pending:
+            self._gather(self.pending.pop(0))
+
+    def _gather(self, j):
+        self.gathered.append(j)
+        if self.gather is not None:
+            self.gather(j)
+
+
+def scan_index(step, handle, slot, n_handles, batch, pool):
+    """which scan of a rank's resident pool a (step, handle, batch slot) processes: consecutive scans, cycled"""
+    return ((step * n_handles + handle) * batch + slot) % pool
+
+
+def shard_frames(n_pairs, rank, world):
+    """tracker leg: frame pair i -> rank i mod world"""
+    return shard(n_pairs, rank, world)

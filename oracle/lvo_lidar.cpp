@@ -75,6 +75,9 @@ struct lvi_lidar {
     std::vector<lvi_pt> mapCornerRaw, mapSurfRaw, mapCornerDS, mapSurfDS;
     lvo::KdTree3f kdCorner, kdSurf;
     bool have_map_raw = false, have_map = false;
+    // ---- batched entry points: the oracle has one pipeline, a batch is a loop over it
+    std::vector<std::vector<lvi_livox_pt>> batch_scans;   // as handed over (point_num entries each)
+    std::vector<lvi_pose_record> batch_records;
     // ---- icp
     float T[6] = {0, 0, 0, 0, 0, 0};                 // transformTobeMapped
     bool isDegenerate = false;
@@ -1084,6 +1087,53 @@ int32_t lvi_debug_residuals(lvi_lidar* h, int32_t which, const float pose[6], lv
 }
 
 // hip-only entry points: present so that the symbol set is identical, but unsupported here
+// ---- batched form: the reference processes scans one by one; a batch is that, n times ----------------------
+int32_t lvi_scan_batch_upload(lvi_lidar* h, int32_t n_scans, const lvi_livox_pt* const* pts, const int32_t* n_raw)
+{
+    if (!h || !pts || !n_raw) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (n_scans < 1 || n_scans > std::max(h->P.batch_scans, 1)) return fail(LVI_ERR_CAPACITY, "n_scans exceeds lvi_lidar_params.batch_scans");
+    for (int z = 0; z < n_scans; z++) {
+        if (n_raw[z] < 0 || (n_raw[z] > 0 && !pts[z])) return fail(LVI_ERR_INVALID_ARG, "bad scan");
+        if (n_raw[z] > h->P.max_raw_points) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
+    }
+    h->batch_scans.resize(n_scans);
+    for (int z = 0; z < n_scans; z++) h->batch_scans[z].assign(pts[z], pts[z] + n_raw[z]);
+    return LVI_OK;
+}
+// "device" memory of the CPU oracle is host memory
+int32_t lvi_scan_batch_bind_device(lvi_lidar* h, int32_t n_scans, const void* const* d_pts, const int32_t* n_raw)
+{
+    return lvi_scan_batch_upload(h, n_scans, reinterpret_cast<const lvi_livox_pt* const*>(d_pts), n_raw);
+}
+int32_t lvi_scan_batch_run(lvi_lidar* h, int32_t n_scans, const float* pose_init, void* d_records, int32_t rebuild_map)
+{
+    if (!h || !pose_init) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (n_scans < 1 || n_scans > (int32_t)h->batch_scans.size()) return fail(LVI_ERR_STATE, "no scan bound / uploaded for a slot");
+    if (rebuild_map && !h->have_map_raw) return fail(LVI_ERR_STATE, "no map uploaded");
+    h->batch_records.assign(n_scans, lvi_pose_record{});
+    for (int z = 0; z < n_scans; z++) {
+        int32_t st = lvi_scan_upload(h, h->batch_scans[z].data(), (int32_t)h->batch_scans[z].size()); if (st < 0) return st;
+        if (rebuild_map) { st = lvi_map_build(h); if (st < 0) return st; }
+        st = lvi_scan_organize(h); if (st < 0) return st;
+        st = lvi_scan_extract(h); if (st < 0) return st;
+        st = lvi_scan_downsample(h); if (st < 0) return st;
+        float pose[6]; lvi_icp_result res;
+        std::memcpy(pose, pose_init + 6 * z, sizeof(pose));
+        st = lvi_scan_match(h, nullptr, pose, &res); if (st < 0) return st;
+        h->batch_records[z] = h->last_record;
+        if (d_records) static_cast<lvi_pose_record*>(d_records)[z] = h->last_record;
+    }
+    return LVI_OK;
+}
+int32_t lvi_scan_batch_get_records(lvi_lidar* h, int32_t n_scans, lvi_pose_record* out)
+{
+    if (!h || !out) return fail(LVI_ERR_INVALID_ARG, "null argument");
+    if (n_scans < 1 || n_scans > (int32_t)h->batch_records.size()) return fail(LVI_ERR_STATE, "batch not run");
+    std::copy(h->batch_records.begin(), h->batch_records.begin() + n_scans, out);
+    return LVI_OK;
+}
+int32_t lvi_batch_select(lvi_lidar* h, int32_t slot) { return (h && slot == 0) ? LVI_OK : fail(LVI_ERR_UNSUPPORTED, "hip only: the oracle keeps the intermediates of the last scan only"); }
+
 int32_t lvi_scan_match_async(lvi_lidar*, const float*, void*) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_scan_upload_device(lvi_lidar*, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_scan_replay_enqueue(lvi_lidar*, const void*, int32_t, const float*, void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }

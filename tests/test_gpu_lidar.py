@@ -772,3 +772,113 @@ def test_device_error_reaches_the_async_record(pkg, hip, scene):
     assert code == A.LVI_ERR_CAPACITY
     assert int(rec[6:7].view(np.int32)[0]) == A.LVI_ERR_CAPACITY
     g.close()
+
+
+# ----------------------------------------------------------------------------- batched launches
+def _dev_buffers(arrays):
+    """copy host arrays to device memory through the HIP runtime liblvi_hip.so links (no torch needed)"""
+    import ctypes as C
+    rt = C.CDLL("libamdhip64.so.7")
+    rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rt.hipFree.argtypes = [C.c_void_p]
+    ptrs = []
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        assert rt.hipMalloc(C.byref(p), max(a.nbytes, 16)) == 0
+        assert rt.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        ptrs.append(p)
+    return rt, ptrs
+
+
+@pytest.mark.parametrize("rebuild", [True, False], ids=["map_rebuilt_per_scan", "frozen_map"])
+def test_batched_launches_are_bit_identical(pkg, hip, scene, rebuild):
+    """lvi_scan_batch_*: S scans of different sizes side by side in one launch sequence (slot in blockIdx.z) give, slot by
+    slot, the bits of the single-scan entry points: pose records, counts, corner indices, labels, DS clouds, DS map"""
+    A = pkg._abi
+    S = pkg.synth
+    NB = 4
+    P = small_params(icp_max_iters=10, icp_disable_break=1)
+    sizes = [20001, 12000, 17003, 9001]
+    poses = [S.loop_pose(0.37 + 0.6 * k, 0.01 * k, -0.01) for k in range(NB)]
+    scans = [S.make_scan(sizes[k], poses[k], 900 + k) for k in range(NB)]
+    guesses = np.stack([S.perturbed_guess(poses[k], 20 + k) for k in range(NB)])
+    # ---- reference: one scan at a time on a plain handle
+    g = pkg.LidarHotpath(hip, **P)
+    g.map_upload(scene["map_corner"], scene["map_surf"]); g.map_build()
+    ref = []
+    for k in range(NB):
+        if rebuild:
+            g.map_build()
+        g.scan_upload(scans[k]); g.scan_organize(); g.scan_extract(); g.scan_downsample()
+        g.scan_match_async(guesses[k], 0)
+        rec = g.get_pose_record()
+        ref.append(dict(rec=rec, counts=g.counts(), ci=g.debug_get(A.DBG_CORNER_INDEX, np.int32), lab=g.debug_get(A.DBG_LABEL, np.int32),
+                        ds=[xyzi(c).view(np.uint32).copy() for c in g.get_scan_ds()], mapds=[xyzi(c).view(np.uint32).copy() for c in g.get_map_ds()]))
+    g.close()
+    # ---- the same four scans as one batch (device-resident scans bound in place, then host scans through staging)
+    b = pkg.LidarHotpath(hip, batch_scans=NB, **P)
+    b.map_upload(scene["map_corner"], scene["map_surf"]); b.map_build()
+    rt, ptrs = _dev_buffers(scans)
+    for form in ("bind", "upload"):
+        for rep in range(2):
+            if form == "bind":
+                b.batch_bind_device([p.value for p in ptrs], sizes)
+            else:
+                b.batch_upload(scans)
+            b.batch_run(guesses, 0, rebuild_map=rebuild)
+            recs = b.batch_get_records(NB)
+            for k in range(NB):
+                np.testing.assert_array_equal(recs[k, :6].view(np.uint32), ref[k]["rec"]["pose"].view(np.uint32))
+                assert int(recs[k, 6:7].view(np.int32)[0]) == 0 and int(recs[k, 7:8].view(np.int32)[0]) == 10
+                b.batch_select(k)
+                assert b.counts() == ref[k]["counts"], (k, b.counts(), ref[k]["counts"])
+                np.testing.assert_array_equal(b.debug_get(A.DBG_CORNER_INDEX, np.int32), ref[k]["ci"])
+                n = ref[k]["counts"]["n"]
+                np.testing.assert_array_equal(b.debug_get(A.DBG_LABEL, np.int32)[5:n - 5], ref[k]["lab"][5:n - 5])
+                for x, y in zip(b.get_scan_ds(), ref[k]["ds"]):
+                    np.testing.assert_array_equal(xyzi(x).view(np.uint32), y)
+                for x, y in zip(b.get_map_ds(), ref[k]["mapds"]):
+                    np.testing.assert_array_equal(xyzi(x).view(np.uint32), y)
+            b.batch_select(0)
+    # a partial batch (fewer scans than slots) and a batch of one
+    b.batch_upload(scans[1:3]); b.batch_run(guesses[1:3], 0, rebuild_map=rebuild)
+    recs = b.batch_get_records(2)
+    for j, k in enumerate((1, 2)):
+        np.testing.assert_array_equal(recs[j, :6].view(np.uint32), ref[k]["rec"]["pose"].view(np.uint32))
+    with pytest.raises(pkg.LviError):
+        b.batch_upload(scans + scans[:1])                 # more scans than batch_scans
+    for p in ptrs:
+        rt.hipFree(p)
+    b.close()
+
+
+def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
+    """from the second GN iteration on the 5-NN search is bounded by the previous neighbours' distances under the new pose
+    (exact: five map points lie inside that ball).  Same records, selected counts and JtJ bits as searching the unit ball"""
+    A = pkg._abi
+    S = pkg.synth
+    out = []
+    for no_bound in ("0", "1"):
+        monkeypatch.setenv("LVI_KNN_NO_BOUND", no_bound)
+        rows = []
+        for kw in (dict(), dict(icp_max_iters=10, icp_disable_break=1)):
+            g = pkg.LidarHotpath(hip, **small_params(**kw))
+            g.map_set(scene["map_corner"], scene["map_surf"])
+            for k in range(3):
+                pose = S.loop_pose(0.37 + 0.8 * k, 0.01, -0.02)
+                g.scan_upload(S.make_scan(20001 - 3000 * k, pose, 60 + k)); g.scan_organize(); g.scan_extract(); g.scan_downsample()
+                r = g.scan_match(S.perturbed_guess(pose, 5 + k))
+                rows.append((bits(r["pose"]), np.array(r["n_sel"]), r["iters"], bits(g.debug_get(A.DBG_ICP_JTJ, np.float32))))
+            cyc = g.debug_get(A.DBG_ICP_CYCLES, np.int64)
+            rows.append((np.array([cyc[14]]),))            # 1: the stamped workgroup of the last launch used a bounded search
+            g.close()
+        out.append(rows)
+    monkeypatch.delenv("LVI_KNN_NO_BOUND")
+    for ra, rb in zip(out[0], out[1]):
+        if len(ra) == 1:
+            assert ra[0][0] == 1 and rb[0][0] == 0
+            continue
+        for x, y in zip(ra, rb):
+            np.testing.assert_array_equal(x, y)

@@ -401,3 +401,31 @@ def test_soft_outcomes_and_errors(pkg, oracle):
     h.map_set(np.ones((30, 4), np.float32), np.ones((30, 4), np.float32))
     assert h.scan_to_map(few, few, np.zeros(6))["status"] == A.LVI_TOO_FEW_FEATURES            # :1320
     h.close()
+
+
+def test_batch_entry_points_are_a_loop(pkg, oracle):
+    """lvi_scan_batch_* on the oracle: the reference processes scans one by one, a batch is exactly that"""
+    from helpers import make_small_scene, small_params
+    S = pkg.synth
+    sc = make_small_scene(pkg, oracle, n_raw=6001, n_kf=5, Horizon_SCAN=2048)
+    P = small_params(Horizon_SCAN=2048, max_raw_points=8192, icp_max_iters=6, icp_disable_break=1, batch_scans=3)
+    poses = [S.loop_pose(0.37 + 0.5 * k) for k in range(3)]
+    scans = [S.make_scan(6001 - 500 * k, poses[k], 70 + k) for k in range(3)]
+    guesses = np.stack([S.perturbed_guess(poses[k], k) for k in range(3)])
+    h = pkg.LidarHotpath(oracle, **P)
+    h.map_upload(sc["map_corner"], sc["map_surf"]); h.map_build()
+    ref = []
+    for k in range(3):
+        h.map_build(); h.scan_upload(scans[k]); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+        ref.append(h.scan_match(guesses[k]))
+    h.batch_upload(scans); h.batch_run(guesses, 0, rebuild_map=True)
+    rec = h.batch_get_records(3)
+    for k in range(3):
+        np.testing.assert_array_equal(rec[k, :6], ref[k]["pose"])
+        assert int(rec[k, 7:8].view(np.int32)[0]) == 6
+    out = np.zeros((3, 8), np.float32)
+    h.batch_run(guesses, out.ctypes.data, rebuild_map=False)          # "device" records of the CPU library are host memory
+    np.testing.assert_array_equal(out, rec)
+    with pytest.raises(pkg.LviError):
+        h.batch_upload(scans + scans)
+    h.close()
