@@ -224,6 +224,8 @@ static void release_slot(LidarDev& d)
     d.arena.release();
     if (d.h_icp) (void)hipHostFree(d.h_icp);
     if (d.h_kfSeg) (void)hipHostFree(d.h_kfSeg);
+    if (d.inc.h_pieces) (void)hipHostFree(d.inc.h_pieces);
+    if (d.inc.h_status) (void)hipHostFree(d.inc.h_status);
     for (int s = 0; s < 2; s++) {
         if (d.h_raw[s]) (void)hipHostFree(d.h_raw[s]);
         if (d.ev_raw[s]) (void)hipEventDestroy(d.ev_raw[s]);
@@ -658,6 +660,7 @@ int32_t lvi_keyframes_clear(lvi_lidar* h)
         LidarDev& d = h->d;
         join_map(d); sync(d);                                        // an assembly in flight still reads the pool
         d.kf_off_c.clear(); d.kf_n_c.clear(); d.kf_off_s.clear(); d.kf_n_s.clear(); d.kf_pose.clear(); d.kf_pool_used = 0;
+        d.inc_ready = false; d.inc_mult.clear(); d.inc_pose.clear();
         return LVI_OK;
     });
 }
@@ -681,7 +684,17 @@ int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_key
 
 int32_t lvi_map_update(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys)
 {
-    return lvi_map_assemble(h, key_indices, n_keys);
+    if (!h || n_keys < 0 || (n_keys > 0 && !key_indices)) return fail(LVI_ERR_INVALID_ARG, "bad key list");
+    for (int i = 0; i < n_keys; i++)
+        if (key_indices[i] < 0 || key_indices[i] >= (int)h->d.kf_pose.size()) return fail(LVI_ERR_INVALID_ARG, "key index out of range");
+    bool done = false;
+    int32_t st = guarded(h, [&]() -> int32_t {
+        done = h->slots.size() == 1 && stage_map_update(h->d, key_indices, n_keys);
+        return LVI_OK;
+    });
+    if (st) return st;
+    if (done) return LVI_OK;
+    return lvi_map_assemble(h, key_indices, n_keys);         // batch handle, range / overflow rule / table full: the full path
 }
 
 int32_t lvi_scan_set_deskew(lvi_lidar* h, const lvi_deskew_info* info)

@@ -1053,32 +1053,113 @@ void stage_map_build(const Slots& sl)
     }
     // raw map counts are host-known here; the voxel plan wants them in device memory
     const VoxelPlan* plans[MAX_BATCH];
-    Batch<GridArgs> G;
     for (int z = 0; z < sl.n; z++) {
         LidarDev& q = sl[z];
         q.n_map_corner = d.n_map_corner; q.n_map_surf = d.n_map_surf;
         q.voxMap.n_host[0] = d.n_map_corner; q.voxMap.n_host[1] = d.n_map_surf; q.voxMap.use_n_host = true;       // instead of a 1-thread launch writing d_dyn
         q.voxMap.bbox_cached = true;
         plans[z] = &q.voxMap;
-        G.a[z] = grid_args(q);
         q.have_map = true;
     }
-    for (int z = sl.n; z < MAX_BATCH; z++) G.a[z] = G.a[0];
     const double n = ((double)d.n_map_corner + (double)d.n_map_surf) * sl.n;
     voxel_downsample_batch(cx, plans, sl.n, "map", n);
-    const double nds = 0.02 * n;     // nominal DS size for byte accounting only
-    const unsigned S = (unsigned)sl.n;
-    LVI_LAUNCH(cx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1, 1, S), dim3(64), 0, cx.stream, G));
-    LVI_LAUNCH(cx, "grid_count", 16.0 * nds, hipLaunchKernelGGL(grid_count_kernel, dim3(GRID_PT_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
-    LVI_LAUNCH(cx, "grid_scan_sum", 0, hipLaunchKernelGGL(grid_scan_sum_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
-    LVI_LAUNCH(cx, "grid_scan_apply", 0, hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
-    LVI_LAUNCH(cx, "grid_scatter", 32.0 * nds, hipLaunchKernelGGL(grid_scatter_kernel, dim3(GRID_PT_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+    stage_map_index(sl, cx);
     if (forked) {
         LVI_HIP(hipEventRecord(d.evMap, cx.stream));
         d.map_pending = true;
     }
 }
 void stage_map_build(LidarDev& d) { stage_map_build(OneSlot(d).s); }
+
+// the replacement of the two KdTreeFLANN::setInputCloud calls (mapOptimization.cpp:1322-1323) over every slot's DS map
+void stage_map_index(const Slots& sl, const Ctx& cx)
+{
+    Batch<GridArgs> G;
+    double nds = 0;
+    for (int z = 0; z < sl.n; z++) { G.a[z] = grid_args(sl[z]); nds += 0.02 * ((double)sl[z].n_map_corner + (double)sl[z].n_map_surf); }   // nominal DS size, byte accounting only
+    for (int z = sl.n; z < MAX_BATCH; z++) G.a[z] = G.a[0];
+    const unsigned S = (unsigned)sl.n;
+    LVI_LAUNCH(cx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1, 1, S), dim3(64), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_count", 16.0 * nds, hipLaunchKernelGGL(grid_count_kernel, dim3(GRID_PT_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_scan_sum", 0, hipLaunchKernelGGL(grid_scan_sum_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_scan_apply", 0, hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+    LVI_LAUNCH(cx, "grid_scatter", 32.0 * nds, hipLaunchKernelGGL(grid_scatter_kernel, dim3(GRID_PT_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
+}
+
+static void kf_matrix(const float* T, float M[12])
+{
+    // pcl::getTransformation(x, y, z, roll, pitch, yaw), transformIn = [roll, pitch, yaw, x, y, z] (:404-407), host libm as the reference
+    const float A = std::cos(T[2]), B = std::sin(T[2]), C = std::cos(T[1]), D = std::sin(T[1]), E = std::cos(T[0]), F = std::sin(T[0]), DE = D * E, DF = D * F;
+    const float R[12] = {A * C, A * DF - B * E, B * F + A * DE, T[3],  B * C, A * E + B * DF, B * DE - A * F, T[4],  -D, C * F, C * E, T[5]};
+    for (int q = 0; q < 12; q++) M[q] = R[q];
+}
+
+// f-4, incremental form.  The key list of this scan against the keyframes the tables already hold: whole keyframes enter
+// (+1) or leave (-1), with multiplicity (the reference's list may name a key twice, :921-927); then the live voxels are
+// emitted for the current bounding box and indexed.  Everything is enqueued on the main stream; one 16-byte read tells
+// the host whether the device accepted (range, table size, PCL's overflow rule) — a sequential node reads the pose of
+// every scan anyway.
+bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys)
+{
+    IncMap& m = d.inc;
+    if (!m.H || n_keys > m.max_active) return false;
+    join_map(d);
+    const int nkf = (int)d.kf_pose.size();
+    std::vector<int> want(nkf, 0);
+    for (int i = 0; i < n_keys; i++) want[keys[i]]++;
+    d.inc_mult.resize(nkf, 0); d.inc_pose.resize(nkf);
+    // a pose corrected since the key was added (correctPoses :1650-1660), or too many dead voxels: start over
+    bool rebuild = !d.inc_ready || d.inc_nocc_bound > m.H / 2;
+    for (int k = 0; k < nkf && !rebuild; k++)
+        if (d.inc_mult[k] > 0 && want[k] > 0 && std::memcmp(d.inc_pose[k].data(), d.kf_pose[k].data(), sizeof(float) * 6) != 0) rebuild = true;
+    LVI_HIP(hipStreamSynchronize(d.ctx.stream));                   // h_pieces / h_status of the previous call have been consumed
+    if (rebuild) { incmap_clear(d.ctx, m); std::fill(d.inc_mult.begin(), d.inc_mult.end(), 0); d.inc_nocc_bound = 0; }
+    int np = 0, maxn = 1;
+    long long added = 0;
+    for (int k = 0; k < nkf; k++) {
+        const int delta = want[k] - d.inc_mult[k];
+        if (!delta) continue;
+        // a key leaves with the pose it entered with
+        float M[12];
+        kf_matrix(delta > 0 ? d.kf_pose[k].data() : d.inc_pose[k].data(), M);
+        for (int rep = 0; rep < std::abs(delta); rep++)
+            for (int which = 0; which < 2; which++) {
+                if (np >= m.max_pieces) return false;
+                IncPiece& pc = m.h_pieces[np++];
+                pc.which = which; pc.sign = delta > 0 ? 1 : -1; pc.kf = k;
+                pc.in_off = which ? d.kf_off_s[k] : d.kf_off_c[k];
+                pc.n = which ? d.kf_n_s[k] : d.kf_n_c[k];
+                for (int q = 0; q < 12; q++) pc.A[q] = M[q];
+                maxn = std::max(maxn, pc.n);
+                if (delta > 0) added += pc.n;
+            }
+        if (delta > 0 && d.inc_mult[k] == 0) d.inc_pose[k] = d.kf_pose[k];
+        d.inc_mult[k] = want[k];
+    }
+    d.inc_nocc_bound = (int)std::min<long long>((long long)d.inc_nocc_bound + added, 0x7fffffff);
+    const float leaf[2] = {d.P.mappingCornerLeafSize, d.P.mappingSurfLeafSize};
+    if (np) {
+        LVI_HIP(hipMemcpyAsync(m.d_pieces, m.h_pieces, sizeof(IncPiece) * (size_t)np, hipMemcpyHostToDevice, d.ctx.stream));
+        incmap_apply(d.ctx, m, d.kfPool, np, maxn, leaf);
+    }
+    // unique active keys for the bounding box
+    std::vector<int> act;
+    long long tc = 0, ts = 0;
+    for (int k = 0; k < nkf; k++) if (want[k] > 0) { act.push_back(k); tc += (long long)want[k] * d.kf_n_c[k]; ts += (long long)want[k] * d.kf_n_s[k]; }
+    if (!act.empty()) LVI_HIP(hipMemcpyAsync(m.d_active, act.data(), sizeof(int) * act.size(), hipMemcpyHostToDevice, d.ctx.stream));
+    incmap_emit(d.ctx, m, (int)act.size(), leaf, d.voxMap.d_grid, d.voxMap.d_nout, d.mapCornerDS, d.mapSurfDS, d.map_cap);
+    d.n_map_corner = (int)std::min<long long>(tc, d.map_cap); d.n_map_surf = (int)std::min<long long>(ts, d.map_cap);
+    stage_map_index(OneSlot(d).s, d.ctx);
+    LVI_HIP(hipMemcpyAsync(m.h_status, m.d_status, sizeof(int), hipMemcpyDeviceToHost, d.ctx.stream));
+    LVI_HIP(hipMemcpyAsync(m.h_status + 1, m.d_nocc, sizeof(int) * 2, hipMemcpyDeviceToHost, d.ctx.stream));
+    LVI_HIP(hipStreamSynchronize(d.ctx.stream));                   // (act / h_pieces are free again)
+    d.inc_nocc_bound = std::max(m.h_status[1], m.h_status[2]);
+    if (m.h_status[0] != 0) { d.inc_ready = false; return false; } // the tables are rebuilt next time; this list goes the full way
+    d.inc_ready = true;
+    d.have_map = true; d.have_map_raw = false;                     // no fused raw cloud exists in this form
+    d.voxMap.bbox_cached = false;
+    return true;
+}
 
 // f-4.  extractCloud's fuse loop (mapOptimization.cpp:931-957): every listed keyframe cloud through
 // transformPointCloud (:347-366) with the key's pose, written at its place in laserCloud{Corner,Surf}FromMap.
@@ -1101,10 +1182,8 @@ void stage_map_assemble(LidarDev& d, const int32_t* keys, int n_keys)
     int oc = 0, os = 0, nseg = 0, maxn = 1;
     for (int i = 0; i < n_keys; i++) {
         const int k = keys[i];
-        const float* T = d.kf_pose[k].data();
-        // pcl::getTransformation(x, y, z, roll, pitch, yaw), transformIn = [roll, pitch, yaw, x, y, z] (:404-407)
-        const float A = std::cos(T[2]), B = std::sin(T[2]), C = std::cos(T[1]), D = std::sin(T[1]), E = std::cos(T[0]), F = std::sin(T[0]), DE = D * E, DF = D * F;
-        const float M[12] = {A * C, A * DF - B * E, B * F + A * DE, T[3],  B * C, A * E + B * DF, B * DE - A * F, T[4],  -D, C * F, C * E, T[5]};
+        float M[12];
+        kf_matrix(d.kf_pose[k].data(), M);
         for (int which = 0; which < 2; which++) {
             LidarDev::KfSeg& sg = d.h_kfSeg[nseg++];
             sg.which = which;

@@ -116,6 +116,12 @@ struct LidarDev {
     // stage flags (host)
     bool have_raw = false, have_org = false, have_feat = false, have_ds = false, have_map_raw = false, have_map = false;
     bool gen_valid = false; int gen_n = 0;
+    // ---- f-4: incremental local map (lvi_map_update); slot 0 of a non-batch handle only
+    IncMap inc;
+    bool inc_ready = false;                                // tables hold exactly inc_mult's keyframes at inc_pose's poses
+    std::vector<int> inc_mult;                             // [n keyframes] multiplicity of the key in the current list
+    std::vector<std::array<float, 6>> inc_pose;            // pose each active key was added with
+    int inc_nocc_bound = 0;                                // upper bound of the occupied slots (tombstones included)
     // batch slots (lvi_lidar_params.batch_scans > 1): slot z > 0 shares slot 0's streams, profiler, keyframe store and RAW
     // local map (the replay configuration: one frozen raw map, re-voxelised and re-indexed for every scan)
     LidarDev* map_owner = nullptr;                         // slot 0 for z > 0
@@ -138,6 +144,8 @@ void stage_downsample(const Slots& s);
 void stage_map_build(const Slots& s);
 void stage_scan_match_enqueue(const Slots& s, const lvi_imu_hint* imu, void* d_records);   // slot z writes its record to d_records + 32 z (when not null)
 void set_pose_init(const Slots& s, const float* pose_init, bool clear_status);          // [n][6]; clear_status: also zero the scan-side device status words
+bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys);       // f-4 incremental: false = not applicable / device said no → the caller assembles
+void stage_map_index(const Slots& s, const Ctx& cx);                     // the KNN grid index over every slot's DS map
 void stage_map_assemble(LidarDev& d, const int32_t* keys, int n_keys);      // f-4: fuse the keyframes into the raw map buffers (the caller builds)
 void stage_organize(LidarDev& d);
 void stage_extract(LidarDev& d);

@@ -732,6 +732,13 @@ void layout(AR& ar, LidarDev& d)
     d.voxGen.allocate(ar, 1, gen_cap, false);
     d.genKeysDbg = ar.template alloc<unsigned>(gen_cap);
     d.kfPool = ar.template alloc<lvi_pt>((size_t)std::max(d.kf_pool_cap, 1));
+    if (d.kf_pool_cap > 0 && d.P.batch_scans <= 1) {
+        // incremental local map: slots for 4x the voxels a full map of this capacity typically leaves (tombstones included; a
+        // table that fills up is rebuilt), (idx, slot) sort pairs for half of them
+        int H = 1 << 16;
+        while (H < d.map_cap / 2 && H < (1 << 22)) H <<= 1;
+        d.inc.allocate(ar, H, std::max(d.P.max_keyframes, 1), d.kf_seg_cap);
+    }
     d.d_kfSeg = ar.template alloc<LidarDev::KfSeg>((size_t)std::max(d.kf_seg_cap, 1));
     d.icp = ar.template alloc<IcpState>(1);
     d.d_pose_init = ar.template alloc<float>(8);
@@ -788,6 +795,10 @@ void lidar_allocate(LidarDev& d)
         LVI_HIP(hipHostMalloc((void**)&d.h_raw[s], sizeof(lvi_livox_pt) * (size_t)d.raw_cap, hipHostMallocDefault));
         LVI_HIP(hipEventCreateWithFlags(&d.ev_raw[s], hipEventDisableTiming));
         LVI_HIP(hipEventRecord(d.ev_raw[s], d.ctx.stream));
+    }
+    if (d.inc.H) {
+        LVI_HIP(hipHostMalloc((void**)&d.inc.h_pieces, sizeof(IncPiece) * (size_t)d.inc.max_pieces, hipHostMallocDefault));
+        LVI_HIP(hipHostMalloc((void**)&d.inc.h_status, sizeof(int) * 4, hipHostMallocDefault));
     }
     LVI_HIP(hipHostMalloc((void**)&d.h_kfSeg, sizeof(LidarDev::KfSeg) * (size_t)std::max(d.kf_seg_cap, 1), hipHostMallocDefault));
     // static segment tables of the voxel plans

@@ -103,25 +103,25 @@ __global__ __launch_bounds__(256) void vox_minmax_kernel(Batch<VoxArgs> B_)
     }
 }
 
+// fixed-point scales of the centroid sums (VoxGrid): from the leaf size and the intensity range only
+__device__ void vox_fx_setup(VoxGrid& g, float leaf, float ilo, float ihi)
+{
+    int ex = 0, exi = 0;
+    (void)frexpf(2.0f * leaf, &ex);                                   // |value - cell * leaf| < 2 leaf <= 2^ex
+    (void)frexpf(fmaxf(fabsf(ilo), fabsf(ihi)), &exi);                // |intensity| < 2^exi
+    g.leaf_d = (double)leaf;
+    g.fx_k = 37 - ex;                                                 // 2^25 points cannot overflow 63 bits
+    g.fx_ki = 37 - max(exi, 8);
+}
+
 // grid geometry of one segment from its bbox (g.bb, g.n_valid already set): PCL's overflow rule, min_b / div_b /
 // divb_mul, key width.  Shared by the multi-workgroup and the single-workgroup paths.
 __device__ void vox_setup_math(VoxGrid& g, float leaf, int seg_cap, float ilo, float ihi, int bin_pts, int bin_max)
 {
     g.overflow = 0; g.nvox = 0; g.out_off = 0;
-    g.ncells = 0ull; g.nbins = 0; g.bin_shift = VB_CL_LOG; g.fx_k = 0; g.fx_ki = 0;
-    g.fx_lo[0] = g.fx_lo[1] = g.fx_lo[2] = g.fx_lo[3] = 0.f;
+    g.ncells = 0ull; g.nbins = 0; g.bin_shift = VB_CL_LOG;
+    vox_fx_setup(g, leaf, ilo, ihi);
     if (g.n_valid == 0) { g.sentinel = 0u; g.nbits = 0; g.inv = 0.f; return; }
-    {
-        // fixed-point scales: every (value - lo) * 2^k stays below 2^38, so 2^25 points cannot overflow 64 bits
-        float ext = 0.f;
-#pragma unroll
-        for (int d = 0; d < 3; d++) { g.fx_lo[d] = ord2f(g.bb[d]); ext = fmaxf(ext, ord2f(g.bb[3 + d]) - ord2f(g.bb[d])); }
-        g.fx_lo[3] = ilo;
-        int ex = 0, exi = 0;
-        (void)frexpf(ext, &ex); (void)frexpf(ihi - ilo, &exi);
-        g.fx_k = 38 - ex;                               // ext < 2^ex
-        g.fx_ki = 38 - exi;
-    }
     const float inv = div_rn(1.0f, leaf);
     g.inv = inv;
     float mnp[3], mxp[3];
@@ -335,21 +335,37 @@ __global__ __launch_bounds__(256) void vox_heads_assign_kernel(Batch<VoxArgs> B_
     }
 }
 
-// Fixed-point image of one coordinate / the exact mean back in f32 (see the header of this file).
-__device__ __forceinline__ unsigned long long fx_of(float v, float lo, int k)
+// Fixed-point image of one coordinate relative to its voxel's own origin / the exact mean back in f32 (VoxGrid, lvi_voxel.hpp)
+__device__ __forceinline__ unsigned long long fx_xyz(float v, int cell, double leaf, int k)
 {
-    return (unsigned long long)__double2ll_rn(ldexp((double)v - (double)lo, k));
+    return (unsigned long long)__double2ll_rn(ldexp((double)v - (double)cell * leaf, k));       // two's complement: sums wrap correctly
 }
-__device__ __forceinline__ float fx_mean(unsigned long long sum, unsigned cnt, float lo, int k)
+__device__ __forceinline__ unsigned long long fx_int(float v, int k) { return (unsigned long long)__double2ll_rn(ldexp((double)v, k)); }
+__device__ __forceinline__ float fx_mean_xyz(unsigned long long sum, unsigned cnt, int cell, double leaf, int k)
 {
-    return (float)((double)lo + ldexp(__ull2double_rn(sum) / (double)cnt, -k));
+    return (float)((double)cell * leaf + ldexp(__ll2double_rn((long long)sum) / (double)cnt, -k));
 }
-__device__ __forceinline__ lvi_pt fx_centroid(const VoxGrid& g, unsigned long long sx, unsigned long long sy, unsigned long long sz,
+__device__ __forceinline__ float fx_mean_int(unsigned long long sum, unsigned cnt, int k) { return (float)ldexp(__ll2double_rn((long long)sum) / (double)cnt, -k); }
+// absolute integer coordinates of a point's voxel: floor(p * inv) — the float floor PCL takes before it subtracts min_b
+__device__ __forceinline__ void vox_cell_abs(const VoxGrid& g, const lvi_pt& p, int c[3])
+{
+    c[0] = (int)floorf(mul_rn(p.x, g.inv)); c[1] = (int)floorf(mul_rn(p.y, g.inv)); c[2] = (int)floorf(mul_rn(p.z, g.inv));
+}
+// … of the voxel with linear idx `key` of this grid
+__device__ __forceinline__ void vox_cell_of_key(const VoxGrid& g, unsigned key, int c[3])
+{
+    const unsigned d0 = (unsigned)g.div_b[0], d1 = (unsigned)g.div_b[1];
+    const unsigned q = key / d0;
+    c[0] = (int)(key - q * d0) + g.min_b[0]; c[1] = (int)(q % d1) + g.min_b[1]; c[2] = (int)(q / d1) + g.min_b[2];
+}
+__device__ __forceinline__ lvi_pt fx_centroid(const VoxGrid& g, unsigned key, unsigned long long sx, unsigned long long sy, unsigned long long sz,
                                               unsigned long long si, unsigned cnt)
 {
+    int c[3];
+    vox_cell_of_key(g, key, c);
     lvi_pt o;
-    o.x = fx_mean(sx, cnt, g.fx_lo[0], g.fx_k); o.y = fx_mean(sy, cnt, g.fx_lo[1], g.fx_k);
-    o.z = fx_mean(sz, cnt, g.fx_lo[2], g.fx_k); o.intensity = fx_mean(si, cnt, g.fx_lo[3], g.fx_ki);
+    o.x = fx_mean_xyz(sx, cnt, c[0], g.leaf_d, g.fx_k); o.y = fx_mean_xyz(sy, cnt, c[1], g.leaf_d, g.fx_k);
+    o.z = fx_mean_xyz(sz, cnt, c[2], g.leaf_d, g.fx_k); o.intensity = fx_mean_int(si, cnt, g.fx_ki);
     return o;
 }
 
@@ -377,10 +393,13 @@ __global__ __launch_bounds__(256) void vox_centroid_kernel(Batch<VoxArgs> B_)
             continue;
         }
         unsigned long long sx = 0, sy = 0, sz = 0, si = 0;
+        const unsigned vkey = act ? sorted_keys(a, s)[b] : 0u;
+        int cell[3];
+        vox_cell_of_key(g, vkey, cell);
         for (int j = b + sub; j < e; j += VOX_CG) {
             const lvi_pt p = in[vals[j]];
-            sx += fx_of(p.x, g.fx_lo[0], g.fx_k); sy += fx_of(p.y, g.fx_lo[1], g.fx_k);
-            sz += fx_of(p.z, g.fx_lo[2], g.fx_k); si += fx_of(p.intensity, g.fx_lo[3], g.fx_ki);
+            sx += fx_xyz(p.x, cell[0], g.leaf_d, g.fx_k); sy += fx_xyz(p.y, cell[1], g.leaf_d, g.fx_k);
+            sz += fx_xyz(p.z, cell[2], g.leaf_d, g.fx_k); si += fx_int(p.intensity, g.fx_ki);
         }
 #pragma unroll
         for (int q = VOX_CG / 2; q > 0; q >>= 1) {
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(256) void vox_centroid_kernel(Batch<VoxArgs> B_)
         }
         if (act && sub == 0) {
             lvi_pt* out = a.concat ? a.st[0].out : a.st[s].out;
-            out[g.out_off + v] = fx_centroid(g, sx, sy, sz, si, (unsigned)(e - b));
+            out[g.out_off + v] = fx_centroid(g, vkey, sx, sy, sz, si, (unsigned)(e - b));
         }
     }
 }
@@ -554,8 +573,10 @@ __device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, cons
             if (!ok[u]) continue;
             const unsigned c = vox_key_of_pt(g, p[u]) - k0;
             if (c >= (unsigned)cells) continue;                         // another sub-range of a wide bin
-            atomicAdd(&L.sx[c], fx_of(p[u].x, g.fx_lo[0], g.fx_k)); atomicAdd(&L.sy[c], fx_of(p[u].y, g.fx_lo[1], g.fx_k));
-            atomicAdd(&L.sz[c], fx_of(p[u].z, g.fx_lo[2], g.fx_k)); atomicAdd(&L.si[c], fx_of(p[u].intensity, g.fx_lo[3], g.fx_ki));
+            int cell[3];
+            vox_cell_abs(g, p[u], cell);
+            atomicAdd(&L.sx[c], fx_xyz(p[u].x, cell[0], g.leaf_d, g.fx_k)); atomicAdd(&L.sy[c], fx_xyz(p[u].y, cell[1], g.leaf_d, g.fx_k));
+            atomicAdd(&L.sz[c], fx_xyz(p[u].z, cell[2], g.leaf_d, g.fx_k)); atomicAdd(&L.si[c], fx_int(p[u].intensity, g.fx_ki));
             atomicAdd(&L.cn[c], 1u);
         }
     }
@@ -576,7 +597,7 @@ __device__ __forceinline__ int vb_emit(const VbCells& L, const VoxGrid& g, lvi_p
     for (int j = 0; j < 4; j++) {
         const int c = tid * 4 + j;
         const unsigned m = c < cells ? L.cn[c] : 0u;
-        if (m) { stg[r] = fx_centroid(g, L.sx[c], L.sy[c], L.sz[c], L.si[c], m); skc[r] = make_uint2(k0 + (unsigned)c, m); r++; }
+        if (m) { stg[r] = fx_centroid(g, k0 + (unsigned)c, L.sx[c], L.sy[c], L.sz[c], L.si[c], m); skc[r] = make_uint2(k0 + (unsigned)c, m); r++; }
     }
     __syncthreads();
     return tot;
@@ -826,6 +847,226 @@ void voxel_debug_fetch(const Ctx& ctx, const VoxelPlan& p, int n_in, std::vector
     keys.resize(n_in);
     LVI_HIP(hipMemcpyAsync(keys.data(), p.sort.keysA, sizeof(unsigned) * n_in, hipMemcpyDeviceToHost, ctx.stream));
     LVI_HIP(hipStreamSynchronize(ctx.stream));
+}
+
+// =====================================================================================================
+// Incremental local map (IncMap, lvi_voxel.hpp)
+// =====================================================================================================
+namespace {
+
+constexpr unsigned long long INC_EMPTY = ~0ull;
+constexpr int INC_BIAS = 1 << 20;                     // voxel coordinates in [-2^20, 2^20): +-209 km at a 0.2 m leaf
+
+struct IncArgs {
+    unsigned long long* key[2]; unsigned long long* sums[2]; int* cnt[2]; int* occ[2]; int* nocc;
+    unsigned* kfBox; const int* active; int n_active;
+    const IncPiece* pieces; const lvi_pt* pool;
+    unsigned *keysA, *valsA, *keysB, *valsB; int sort_cap;
+    int *d_n, *d_nbits, *status;
+    VoxGrid* grid; int* nout; lvi_pt* out[2];
+    float leaf[2]; float inv[2]; int fx_k[2]; int H, seg_cap;
+};
+
+__device__ __forceinline__ unsigned inc_hash(unsigned long long k, int H)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (unsigned)k & (unsigned)(H - 1);
+}
+
+__global__ __launch_bounds__(256) void inc_clear_kernel(IncArgs a)
+{
+    const int w = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.H; i += gridDim.x * 256) {
+        a.key[w][i] = INC_EMPTY; a.cnt[w][i] = 0;
+        a.sums[w][4 * (size_t)i] = 0ull; a.sums[w][4 * (size_t)i + 1] = 0ull; a.sums[w][4 * (size_t)i + 2] = 0ull; a.sums[w][4 * (size_t)i + 3] = 0ull;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.nocc[w] = 0; if (w == 0) a.status[0] = 0; }
+}
+
+// blockIdx.y = piece; every point of the piece goes through transformPointCloud's expression (as kf_assemble) and into its voxel
+__global__ __launch_bounds__(256) void inc_apply_kernel(IncArgs a)
+{
+    const IncPiece pc = a.pieces[blockIdx.y];
+    const int w = pc.which;
+    const float inv = a.inv[w];
+    const double leaf = (double)a.leaf[w];
+    const int k = a.fx_k[w];
+    const lvi_pt* __restrict__ in = a.pool + pc.in_off;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, imax = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < pc.n; i += gridDim.x * 256) {
+        const lvi_pt p = in[i];
+        lvi_pt q;
+        q.x = pc.A[0] * p.x + pc.A[1] * p.y + pc.A[2] * p.z + pc.A[3];            // pointAssociateToMap / transformPointCloud :339-366
+        q.y = pc.A[4] * p.x + pc.A[5] * p.y + pc.A[6] * p.z + pc.A[7];
+        q.z = pc.A[8] * p.x + pc.A[9] * p.y + pc.A[10] * p.z + pc.A[11];
+        q.intensity = p.intensity;
+        const int c0 = (int)floorf(mul_rn(q.x, inv)), c1 = (int)floorf(mul_rn(q.y, inv)), c2 = (int)floorf(mul_rn(q.z, inv));
+        if (pc.sign > 0) {
+            mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+            mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+            imax = fmaxf(imax, fabsf(q.intensity));
+        }
+        if (c0 < -INC_BIAS || c0 >= INC_BIAS || c1 < -INC_BIAS || c1 >= INC_BIAS || c2 < -INC_BIAS || c2 >= INC_BIAS || !(fabsf(q.intensity) < 256.f)) {
+            atomicOr(a.status, !(fabsf(q.intensity) < 256.f) ? INC_ERR_INTENSITY : INC_ERR_RANGE);
+            continue;
+        }
+        const unsigned long long key = ((unsigned long long)(c2 + INC_BIAS) << 42) | ((unsigned long long)(c1 + INC_BIAS) << 21) | (unsigned long long)(c0 + INC_BIAS);
+        unsigned h = inc_hash(key, a.H);
+        int slot = -1;
+        for (int probe = 0; probe < a.H; probe++) {
+            const unsigned long long cur = a.key[w][h];
+            if (cur == key) { slot = (int)h; break; }
+            if (cur == INC_EMPTY) {
+                const unsigned long long old = atomicCAS(&a.key[w][h], INC_EMPTY, key);
+                if (old == INC_EMPTY) { slot = (int)h; a.occ[w][atomicAdd(&a.nocc[w], 1)] = slot; break; }
+                if (old == key) { slot = (int)h; break; }
+            }
+            h = (h + 1) & (unsigned)(a.H - 1);
+        }
+        if (slot < 0) { atomicOr(a.status, INC_ERR_FULL); continue; }
+        unsigned long long v[4] = {fx_xyz(q.x, c0, leaf, k), fx_xyz(q.y, c1, leaf, k), fx_xyz(q.z, c2, leaf, k), fx_int(q.intensity, 37 - 8)};
+        unsigned long long* sm = a.sums[w] + 4 * (size_t)slot;
+#pragma unroll
+        for (int j = 0; j < 4; j++) atomicAdd(&sm[j], pc.sign > 0 ? v[j] : (0ull - v[j]));
+        atomicAdd(&a.cnt[w][slot], pc.sign);
+    }
+    if (pc.sign > 0) {
+        // map-frame bbox of this keyframe cloud (folded over the active keys at every emission)
+        __shared__ float smn[4][3], smx[4][3], sim[4];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+        imax = wave_max(imax);
+        if (lane_id() == 0) { for (int d = 0; d < 3; d++) { smn[wave_id()][d] = mn[d]; smx[wave_id()][d] = mx[d]; } sim[wave_id()] = imax; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int d = threadIdx.x;
+            const float lo = fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d])), hi = fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]));
+            unsigned* box = a.kfBox + ((size_t)pc.kf * 2 + w) * 8;
+            if (lo <= hi) { atomicMin(&box[d], f2ord(lo)); atomicMax(&box[3 + d], f2ord(hi)); }
+        }
+    }
+}
+
+// per keyframe record reset before it is (re)added: min = +inf, max = -inf, n = points
+__global__ void inc_box_reset_kernel(IncArgs a, int n_pieces)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pieces) return;
+    const IncPiece pc = a.pieces[i];
+    if (pc.sign <= 0) return;
+    unsigned* box = a.kfBox + ((size_t)pc.kf * 2 + pc.which) * 8;
+    box[0] = box[1] = box[2] = 0xFFFFFFFFu; box[3] = box[4] = box[5] = 0u; box[6] = (unsigned)pc.n; box[7] = 0u;
+}
+
+// one wavefront per map kind: bbox of the active keyframes -> VoxGrid (the geometry vox_setup derives from the fused cloud)
+__global__ __launch_bounds__(64) void inc_setup_kernel(IncArgs a, int bin_pts, int bin_max)
+{
+    const int w = blockIdx.x;
+    VoxGrid& g = a.grid[w];
+    unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    long long n = 0;
+    for (int i = threadIdx.x; i < a.n_active; i += 64) {
+        const unsigned* box = a.kfBox + ((size_t)a.active[i] * 2 + w) * 8;
+        if (box[6] == 0u) continue;
+#pragma unroll
+        for (int d = 0; d < 3; d++) { lo[d] = min(lo[d], box[d]); hi[d] = max(hi[d], box[3 + d]); }
+        n += box[6];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) { lo[d] = min(lo[d], (unsigned)__shfl_xor((int)lo[d], o, 64)); hi[d] = max(hi[d], (unsigned)__shfl_xor((int)hi[d], o, 64)); }
+        n += __shfl_xor(n, o, 64);
+    }
+    if (threadIdx.x != 0) return;
+    g.n_valid = (int)min(n, (long long)0x7fffffff);
+    if (n > 0) { for (int d = 0; d < 3; d++) { g.bb[d] = lo[d]; g.bb[3 + d] = hi[d]; } }
+    else { g.bb[0] = g.bb[1] = g.bb[2] = 0xFFFFFFFFu; g.bb[3] = g.bb[4] = g.bb[5] = 0u; }
+    vox_setup_math(g, a.leaf[w], a.seg_cap, 0.f, 255.f, bin_pts, bin_max);         // intensities were checked to be < 256: fx_ki = 29
+    if (g.overflow) atomicOr(a.status, INC_ERR_OVERFLOW);
+    a.d_nbits[w] = g.nbits;
+    a.d_n[w] = 0;
+}
+
+// (idx under the current grid, slot) of every live voxel, in any order (the sort fixes it; idx is unique per voxel)
+__global__ __launch_bounds__(256) void inc_keys_kernel(IncArgs a)
+{
+    const int w = blockIdx.y;
+    const VoxGrid& g = a.grid[w];
+    const int nocc = a.nocc[w];
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < nocc; j += gridDim.x * 256) {
+        const int slot = a.occ[w][j];
+        if (a.cnt[w][slot] <= 0) continue;
+        const unsigned long long key = a.key[w][slot];
+        const int c0 = (int)(key & 0x1FFFFFull) - INC_BIAS, c1 = (int)((key >> 21) & 0x1FFFFFull) - INC_BIAS, c2 = (int)(key >> 42) - INC_BIAS;
+        const unsigned idx = (unsigned)(c0 - g.min_b[0]) + (unsigned)(c1 - g.min_b[1]) * g.mul1 + (unsigned)(c2 - g.min_b[2]) * g.mul2;
+        const int pos = atomicAdd(&a.d_n[w], 1);
+        if (pos >= a.sort_cap) { atomicOr(a.status, INC_ERR_FULL); continue; }
+        a.keysA[(size_t)w * a.sort_cap + pos] = idx; a.valsA[(size_t)w * a.sort_cap + pos] = (unsigned)slot;
+    }
+}
+
+__global__ __launch_bounds__(256) void inc_out_kernel(IncArgs a)
+{
+    const int w = blockIdx.y;
+    VoxGrid& g = a.grid[w];
+    const int n = min(a.d_n[w], a.sort_cap);
+    const bool inB = rs_result_in_B(a.d_nbits[w]);
+    const unsigned* keys = (inB ? a.keysB : a.keysA) + (size_t)w * a.sort_cap;
+    const unsigned* vals = (inB ? a.valsB : a.valsA) + (size_t)w * a.sort_cap;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        const int slot = (int)vals[r];
+        const unsigned long long* sm = a.sums[w] + 4 * (size_t)slot;
+        a.out[w][r] = fx_centroid(g, keys[r], sm[0], sm[1], sm[2], sm[3], (unsigned)a.cnt[w][slot]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g.nvox = n; g.out_off = 0; a.nout[w] = n;
+        if (w == 1) a.nout[2] = a.d_n[0] + n;
+    }
+}
+
+IncArgs inc_args(const IncMap& m, const float leaf[2])
+{
+    IncArgs a{};
+    for (int w = 0; w < 2; w++) {
+        a.key[w] = m.key[w]; a.sums[w] = m.sums[w]; a.cnt[w] = m.cnt[w]; a.occ[w] = m.occ[w];
+        a.leaf[w] = leaf[w]; a.inv[w] = 1.0f / leaf[w];
+        int ex = 0; (void)frexpf(2.0f * leaf[w], &ex); a.fx_k[w] = 37 - ex;          // vox_fx_setup
+    }
+    a.nocc = m.d_nocc; a.kfBox = m.kfBox; a.active = m.d_active; a.pieces = m.d_pieces;
+    a.keysA = m.sort.keysA; a.valsA = m.sort.valsA; a.keysB = m.sort.keysB; a.valsB = m.sort.valsB; a.sort_cap = m.sort.seg_cap;
+    a.d_n = m.d_n; a.d_nbits = m.d_nbits; a.status = m.d_status; a.H = m.H;
+    return a;
+}
+
+}  // namespace
+
+void incmap_clear(const Ctx& ctx, const IncMap& m)
+{
+    const float leaf[2] = {1.f, 1.f};
+    IncArgs a = inc_args(m, leaf);
+    LVI_LAUNCH(ctx, "inc_clear", 48.0 * m.H * 2, hipLaunchKernelGGL(inc_clear_kernel, dim3(std::min(div_up(m.H, 256), 2048), 2), dim3(256), 0, ctx.stream, a));
+}
+
+void incmap_apply(const Ctx& ctx, const IncMap& m, const lvi_pt* pool, int n_pieces, int max_n, const float leaf[2])
+{
+    if (n_pieces <= 0) return;
+    IncArgs a = inc_args(m, leaf);
+    a.pool = pool;
+    LVI_LAUNCH(ctx, "inc_box_reset", 0, hipLaunchKernelGGL(inc_box_reset_kernel, dim3(div_up(n_pieces, 64)), dim3(64), 0, ctx.stream, a, n_pieces));
+    LVI_LAUNCH(ctx, "inc_apply", 0, hipLaunchKernelGGL(inc_apply_kernel, dim3(std::max(1, std::min(div_up(max_n, 256), 32)), n_pieces), dim3(256), 0, ctx.stream, a));
+}
+
+void incmap_emit(const Ctx& ctx, const IncMap& m, int n_active, const float leaf[2], VoxGrid* grid, int* nout, lvi_pt* outC, lvi_pt* outS, int seg_cap)
+{
+    IncArgs a = inc_args(m, leaf);
+    a.n_active = n_active; a.grid = grid; a.nout = nout; a.out[0] = outC; a.out[1] = outS; a.seg_cap = seg_cap;
+    const VoxelPlan defaults;
+    LVI_LAUNCH(ctx, "inc_setup", 0, hipLaunchKernelGGL(inc_setup_kernel, dim3(2), dim3(64), 0, ctx.stream, a, defaults.bin_pts, defaults.bin_max));
+    const dim3 gk(std::min(div_up(m.H, 256), 1024), 2);
+    LVI_LAUNCH(ctx, "inc_keys", 0, hipLaunchKernelGGL(inc_keys_kernel, gk, dim3(256), 0, ctx.stream, a));
+    radix_sort_pairs(ctx, m.sort, m.d_n, m.d_nbits, 4, "inc", 0.0);
+    LVI_LAUNCH(ctx, "inc_out", 0, hipLaunchKernelGGL(inc_out_kernel, gk, dim3(256), 0, ctx.stream, a));
 }
 
 void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)

@@ -26,10 +26,12 @@ struct VoxGrid {                 // device, per segment
     int overflow;                // PCL's "leaf size too small" rule hit: output = input
     int nvox;
     int out_off;
-    // ---- centroid arithmetic (both paths): exact integer sums of (value - fx_lo) * 2^fx_k, so the result does not
-    //      depend on the order the points of a voxel are visited in
-    float fx_lo[4];              // bbox min x,y,z and min intensity
-    int fx_k, fx_ki;             // fixed-point scale exponents of xyz / intensity
+    // ---- centroid arithmetic (every realisation, the incremental map included): exact integer sums of
+    //      (value - cell * leaf) * 2^fx_k per voxel, cell = the voxel's ABSOLUTE integer coordinate floor(value * inv): the origin
+    //      of a voxel's sums is a property of the voxel, not of the bounding box, so the sums do not depend on which other points
+    //      are in the cloud, nor on the order the points of a voxel are visited in.  Intensity: value * 2^fx_ki (origin 0).
+    double leaf_d;               // (double)leaf
+    int fx_k, fx_ki;             // scale exponents: |value - cell*leaf| < 2 leaf < 2^(37 - fx_k); |intensity| < 2^(37 - fx_ki), at least 2^8
     // ---- binned path: bin = idx >> bin_shift, nbins <= VB_NB
     int bin_shift, nbins;
     unsigned long long ncells;   // div_b product (0 when the overflow rule fired or the segment is empty)
@@ -118,6 +120,53 @@ struct VoxelPlan {
     void release();                                                            // frees h_ncells
     void set_static(const Ctx& ctx, const VoxSegStatic* host_segs);           // H2D of the per-segment pointers (+ the pinned hint)
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Incremental local map: the two VoxelGrids of extractCloud (mapOptimization.cpp:958-965) kept as
+// persistent per-voxel sums.  A voxel's membership — floor(p * inv_leaf) per axis — and its sums — relative to the voxel's
+// own origin — do not depend on the bounding box, so whole keyframes can be added to and taken from the sums; an emission
+// computes PCL's linear idx of every live voxel for the CURRENT bounding box, sorts by it and writes the centroids: the same
+// voxels, order and bits as filtering the fused cloud.  One open-addressing table per map kind (corner, surf).
+struct IncPiece { int in_off, n, which, sign, kf; float A[12]; };      // one (keyframe, corner|surf) cloud to add (+1) or take out (-1)
+enum { INC_ERR_RANGE = 1, INC_ERR_FULL = 2, INC_ERR_OVERFLOW = 4, INC_ERR_INTENSITY = 8 };
+struct IncMap {
+    int H = 0;                                // slots per table (power of two)
+    int max_kf = 0;
+    unsigned long long* key[2] = {nullptr, nullptr};       // [H] packed absolute voxel coordinates, ~0 = empty
+    unsigned long long* sums[2] = {nullptr, nullptr};      // [H][4]
+    int* cnt[2] = {nullptr, nullptr};                      // [H] points in the voxel (0: a voxel every keyframe has left)
+    int* occ[2] = {nullptr, nullptr};                      // [H] slots in first-touch order
+    int* d_nocc = nullptr;                                 // [2]
+    unsigned* kfBox = nullptr;                             // [max_kf][2][8] map-frame bbox of a stored keyframe at the pose it was added with
+    int* d_active = nullptr;                               // [max_active] key indices of the current list (bbox fold)
+    int max_active = 0;
+    IncPiece* d_pieces = nullptr; IncPiece* h_pieces = nullptr; int max_pieces = 0;
+    SortPlan sort;                                         // (idx, slot) pairs of the live voxels, 2 segments
+    int *d_n = nullptr, *d_nbits = nullptr;                // [2]
+    int* d_status = nullptr;                               // INC_ERR_* (sticky until cleared)
+    int* h_status = nullptr;                               // pinned: [0] status, [1..2] n_occ
+    template <class AR> void allocate(AR& ar, int H_, int max_kf_, int max_active_)
+    {
+        H = H_; max_kf = max_kf_; max_active = max_active_; max_pieces = 4 * max_active_ + 16;
+        for (int w = 0; w < 2; w++) {
+            key[w] = ar.template alloc<unsigned long long>(H); sums[w] = ar.template alloc<unsigned long long>((size_t)H * 4);
+            cnt[w] = ar.template alloc<int>(H); occ[w] = ar.template alloc<int>(H);
+        }
+        d_nocc = ar.template alloc<int>(2);
+        kfBox = ar.template alloc<unsigned>((size_t)std::max(max_kf, 1) * 16);
+        d_active = ar.template alloc<int>(std::max(max_active, 1));
+        d_pieces = ar.template alloc<IncPiece>(max_pieces);
+        sort.allocate(ar, 2, H / 2);
+        d_n = ar.template alloc<int>(2); d_nbits = ar.template alloc<int>(2);
+        d_status = ar.template alloc<int>(4);
+    }
+};
+void incmap_clear(const Ctx& ctx, const IncMap& m);
+// add / remove the listed keyframe clouds (pool = the keyframe store)
+void incmap_apply(const Ctx& ctx, const IncMap& m, const lvi_pt* pool, int n_pieces, int max_n, const float leaf[2]);
+// emit the live voxels of both tables as laserCloud{Corner,Surf}FromMapDS: fills grid[2] / nout[3] / out[2] exactly as
+// voxel_downsample_batch of the fused cloud would (n_active unique keys of d_active give the bounding box)
+void incmap_emit(const Ctx& ctx, const IncMap& m, int n_active, const float leaf[2], VoxGrid* grid, int* nout, lvi_pt* outC, lvi_pt* outS, int seg_cap);
 
 // Enqueue the whole filter for every segment.  Two interchangeable realisations with bit-identical output:
 //   SORTED  stable radix sort of (voxel idx, point index) + ordered head compaction + per-voxel sums; any grid.
