@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-tracker", action="store_true")
     ap.add_argument("--tracker-seconds", type=float, default=0.6)
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--sequential-scans", type=int, default=48,
+                    help="secondary figure (rank 0): a sequential replay — raw stream -> pose -> keyframe -> next scan — through the C++ node "
+                         "code (host/lvi_host.hpp) with the incremental local map and with the full per-scan assembly; 0 = skip")
     return ap.parse_args()
 
 
@@ -266,6 +269,14 @@ def main():
         except Exception as e:                      # noqa: BLE001 — the tracker leg must not hide the headline
             tracker_out = dict(error=str(e))
 
+    # ---------------------------------------------------------------- sequential mode (secondary figure, rank 0)
+    seq_out = None
+    if args.sequential_scans > 0 and rank == 0:
+        try:
+            seq_out = bench_sequential(pkg, hip, local_rank, dev, args.sequential_scans, args.n_raw, args.keyframes, args.kf_n_raw)
+        except Exception as e:                      # noqa: BLE001
+            seq_out = dict(error=str(e))
+
     # ---------------------------------------------------------------- per-kernel timing with HIP events (same workload, same process)
     # (only handle 0 records events; the other handles keep running beside it as in the timed pass)
     stats, kern_ms = [], 0.0
@@ -362,6 +373,8 @@ def main():
     )
     if tracker_out is not None:
         out["tracker"] = tracker_out
+    if seq_out is not None:
+        out["sequential"] = seq_out
 
     # ---------------------------------------------------------------- CPU baseline: the oracle on this host's cores (rank 0, N=1)
     if world == 1 and rank == 0 and not args.no_cpu:
@@ -427,6 +440,75 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_sequential(pkg, hip, device, dev, n_scans, n_raw, n_keyframes, kf_n_raw):
+    """The production shape of the path (strictly sequential): every scan is matched against the local map its
+    predecessors built.  Scans (resident in HBM) go one by one through MapOptimizationNode of host/lvi_host.hpp — C++ over the
+    C-ABI: updateInitialGuess, extractNearby, map (incremental lvi_map_update | full lvi_map_assemble), scan matching with the
+    reference's break rule, saveFrame / keyframe push — with one host sync per scan (the pose decides what happens next).
+    Two map sizes: the organic one (only the keyframes this run saves) and the BASELINE one (the node starts with the
+    --keyframes keyframes of the headline's local map in its store, all inside the search radius: a ~5 M-point local map)."""
+    import torch
+    S, H = pkg.synth, pkg.host_api
+    hl = pkg.load_host()
+    poses = [S.loop_pose(0.3 + 0.027 * k, 0.003 * np.sin(k), -0.003 * np.cos(k)) for k in range(n_scans)]      # 0.26 m per scan: a keyframe every 4th
+    d_scans = []
+    for k in range(n_scans):
+        sc = S.make_scan(n_raw, poses[k], 5000 + k, torch_device=dev)
+        d_scans.append(torch.from_numpy(sc.view(np.uint8).reshape(-1, 20).copy()).to(dev))
+    torch.cuda.synchronize()
+    P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=6_500_000, max_keyframes=512, max_keyframe_points=6_500_000)
+    seeds = []
+    ex = pkg.LidarHotpath(hip, device=device, N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=1 << 16)
+    S.make_map(ex, n_keyframes, kf_n_raw, seed=4711, torch_device=dev, keyframes_out=seeds)
+    ex.close()
+    out = {}
+    for size in ("organic_map", "baseline_map"):
+        sec = {}
+        ref_pose = None
+        for name, inc in (("incremental_map", 1), ("full_assembly_per_scan", 0)):
+            # density 0.05 m for the seeded run: every stored key pose survives extractNearby's pose downsampling → all keyframes fused
+            m = H.SequentialMapper(hl, hip, pkg.default_params(hip, **P), device=device, incremental_map=inc,
+                                   keyframe_density=(0.05 if size == "baseline_map" else 2.0))
+            if size == "baseline_map":
+                # seeded in loop order, ending with the keyframe next to the first scan: the node's pose after seeding is that key's
+                d0 = [float(np.linalg.norm(np.asarray(pose[3:6], np.float64) - poses[0][3:6])) for (_, _, pose) in seeds]
+                k0 = int(np.argmin(d0))
+                order = list(range(k0 + 1, len(seeds))) + list(range(0, k0 + 1))
+                for i in order:
+                    c, s_, pose = seeds[i]
+                    m.seed_keyframe(c, s_, pose, 0.0)
+            t_scan, res = [], []
+            # seeded: the stream continues in the map frame of the seeds (true poses); organic: it starts at the first scan
+            for k in range(n_scans):
+                t0 = time.perf_counter()
+                r = m.scan_device(d_scans[k].data_ptr(), n_raw, 10.0 + 0.2 * k)
+                t_scan.append(time.perf_counter() - t0)
+                res.append(r)
+            steady = t_scan[n_scans // 4:]
+            # GPU time the local map costs per scan in this form (HIP events, a few more scans of the same stream replayed in place)
+            m.handle.prof_reset(); m.handle.prof_enable(True)
+            n_prof = 6
+            for k in range(n_prof):
+                m.scan_device(d_scans[n_scans - 1].data_ptr(), n_raw, 10.0 + 0.2 * (n_scans + k))
+            st = m.handle.prof_read(); m.handle.prof_enable(False)
+            is_map = lambda nm: nm.startswith(("inc_", "kf_assemble", "grid_")) or nm.endswith(("/map", "/inc"))
+            map_us = sum(1e3 * x["total_ms"] for x in st if is_map(x["name"])) / n_prof
+            all_us = sum(1e3 * x["total_ms"] for x in st) / n_prof
+            sec[name] = dict(scans_per_sec=round(len(steady) / sum(steady), 1), ms_per_scan_median=round(1e3 * float(np.median(steady)), 3),
+                             keyframes=res[-1]["n_keyframes"], keys_in_last_map=res[-1]["n_keys"], iters_last=res[-1]["iters"],
+                             map_ds_points=m.handle.counts()["map_surf_ds"] + m.handle.counts()["map_corner_ds"], status_last=res[-1]["status"],
+                             local_map_kernel_us_per_scan=round(map_us, 1), all_kernel_us_per_scan=round(all_us, 1))
+            if ref_pose is None:
+                ref_pose = res[-1]["pose"]
+            else:
+                sec["poses_bit_identical_between_forms"] = bool((res[-1]["pose"].view(np.uint32) == ref_pose.view(np.uint32)).all())
+            m.close()
+        out[size] = sec
+    out["config"] = dict(scans=n_scans, n_raw=n_raw, spacing_m=0.26, seeded_keyframes=len(seeds),
+                         note="reference break rule (<= 20 iterations), one host sync per scan; not the headline workload")
+    return out
 
 
 def bench_tracker(pkg, hip, device, rank, world, dist, dev, seconds):

@@ -226,6 +226,7 @@ static void release_slot(LidarDev& d)
     if (d.h_kfSeg) (void)hipHostFree(d.h_kfSeg);
     if (d.inc.h_pieces) (void)hipHostFree(d.inc.h_pieces);
     if (d.inc.h_status) (void)hipHostFree(d.inc.h_status);
+    if (d.inc.h_active) (void)hipHostFree(d.inc.h_active);
     for (int s = 0; s < 2; s++) {
         if (d.h_raw[s]) (void)hipHostFree(d.h_raw[s]);
         if (d.ev_raw[s]) (void)hipEventDestroy(d.ev_raw[s]);

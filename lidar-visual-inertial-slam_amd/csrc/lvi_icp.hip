@@ -1104,6 +1104,14 @@ bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys)
     IncMap& m = d.inc;
     if (!m.H || n_keys > m.max_active) return false;
     join_map(d);
+    // like the full build, the update runs on the handle's second stream unless map_on_main_stream: it overlaps the scan-side
+    // stages already enqueued on the main stream, and the host waits for THIS stream only
+    const Ctx& cx = d.P.map_on_main_stream ? d.ctx : d.ctx2;
+    const bool forked = cx.stream != d.ctx.stream;
+    if (forked) {
+        LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));            // the previous scan's GN loop still reads the previous index
+        LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
+    }
     const int nkf = (int)d.kf_pose.size();
     std::vector<int> want(nkf, 0);
     for (int i = 0; i < n_keys; i++) want[keys[i]]++;
@@ -1112,8 +1120,7 @@ bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys)
     bool rebuild = !d.inc_ready || d.inc_nocc_bound > m.H / 2;
     for (int k = 0; k < nkf && !rebuild; k++)
         if (d.inc_mult[k] > 0 && want[k] > 0 && std::memcmp(d.inc_pose[k].data(), d.kf_pose[k].data(), sizeof(float) * 6) != 0) rebuild = true;
-    LVI_HIP(hipStreamSynchronize(d.ctx.stream));                   // h_pieces / h_status of the previous call have been consumed
-    if (rebuild) { incmap_clear(d.ctx, m); std::fill(d.inc_mult.begin(), d.inc_mult.end(), 0); d.inc_nocc_bound = 0; }
+    if (rebuild) { incmap_clear(cx, m); std::fill(d.inc_mult.begin(), d.inc_mult.end(), 0); d.inc_nocc_bound = 0; }
     int np = 0, maxn = 1;
     long long added = 0;
     for (int k = 0; k < nkf; k++) {
@@ -1124,7 +1131,7 @@ bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys)
         kf_matrix(delta > 0 ? d.kf_pose[k].data() : d.inc_pose[k].data(), M);
         for (int rep = 0; rep < std::abs(delta); rep++)
             for (int which = 0; which < 2; which++) {
-                if (np >= m.max_pieces) return false;
+                if (np >= m.max_pieces) { d.inc_ready = false; return false; }
                 IncPiece& pc = m.h_pieces[np++];
                 pc.which = which; pc.sign = delta > 0 ? 1 : -1; pc.kf = k;
                 pc.in_off = which ? d.kf_off_s[k] : d.kf_off_c[k];
@@ -1139,20 +1146,23 @@ bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys)
     d.inc_nocc_bound = (int)std::min<long long>((long long)d.inc_nocc_bound + added, 0x7fffffff);
     const float leaf[2] = {d.P.mappingCornerLeafSize, d.P.mappingSurfLeafSize};
     if (np) {
-        LVI_HIP(hipMemcpyAsync(m.d_pieces, m.h_pieces, sizeof(IncPiece) * (size_t)np, hipMemcpyHostToDevice, d.ctx.stream));
-        incmap_apply(d.ctx, m, d.kfPool, np, maxn, leaf);
+        LVI_HIP(hipMemcpyAsync(m.d_pieces, m.h_pieces, sizeof(IncPiece) * (size_t)np, hipMemcpyHostToDevice, cx.stream));
+        incmap_apply(cx, m, d.kfPool, np, maxn, leaf);
     }
-    // unique active keys for the bounding box
-    std::vector<int> act;
+    // unique active keys for the bounding box (pinned staging: the tail of h_pieces' allocation)
+    int na = 0;
     long long tc = 0, ts = 0;
-    for (int k = 0; k < nkf; k++) if (want[k] > 0) { act.push_back(k); tc += (long long)want[k] * d.kf_n_c[k]; ts += (long long)want[k] * d.kf_n_s[k]; }
-    if (!act.empty()) LVI_HIP(hipMemcpyAsync(m.d_active, act.data(), sizeof(int) * act.size(), hipMemcpyHostToDevice, d.ctx.stream));
-    incmap_emit(d.ctx, m, (int)act.size(), leaf, d.voxMap.d_grid, d.voxMap.d_nout, d.mapCornerDS, d.mapSurfDS, d.map_cap);
+    for (int k = 0; k < nkf; k++) if (want[k] > 0) { m.h_active[na++] = k; tc += (long long)want[k] * d.kf_n_c[k]; ts += (long long)want[k] * d.kf_n_s[k]; }
+    if (na) LVI_HIP(hipMemcpyAsync(m.d_active, m.h_active, sizeof(int) * (size_t)na, hipMemcpyHostToDevice, cx.stream));
+    incmap_emit(cx, m, na, leaf, d.voxMap.d_grid, d.voxMap.d_nout, d.mapCornerDS, d.mapSurfDS, d.map_cap);
     d.n_map_corner = (int)std::min<long long>(tc, d.map_cap); d.n_map_surf = (int)std::min<long long>(ts, d.map_cap);
-    stage_map_index(OneSlot(d).s, d.ctx);
-    LVI_HIP(hipMemcpyAsync(m.h_status, m.d_status, sizeof(int), hipMemcpyDeviceToHost, d.ctx.stream));
-    LVI_HIP(hipMemcpyAsync(m.h_status + 1, m.d_nocc, sizeof(int) * 2, hipMemcpyDeviceToHost, d.ctx.stream));
-    LVI_HIP(hipStreamSynchronize(d.ctx.stream));                   // (act / h_pieces are free again)
+    stage_map_index(OneSlot(d).s, cx);
+    LVI_HIP(hipMemcpyAsync(m.h_status, m.d_status, sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+    LVI_HIP(hipMemcpyAsync(m.h_status + 1, m.d_nocc, sizeof(int) * 2, hipMemcpyDeviceToHost, cx.stream));
+    if (forked) { LVI_HIP(hipEventRecord(d.evMap, cx.stream)); d.map_pending = true; }
+    // one 12-byte read tells the host whether the device accepted the lists (range, table size, PCL's overflow rule): it
+    // waits for the map stream only — the scan-side stages keep running on the main stream
+    LVI_HIP(hipStreamSynchronize(cx.stream));
     d.inc_nocc_bound = std::max(m.h_status[1], m.h_status[2]);
     if (m.h_status[0] != 0) { d.inc_ready = false; return false; } // the tables are rebuilt next time; this list goes the full way
     d.inc_ready = true;

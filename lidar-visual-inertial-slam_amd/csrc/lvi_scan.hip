@@ -799,6 +799,7 @@ void lidar_allocate(LidarDev& d)
     if (d.inc.H) {
         LVI_HIP(hipHostMalloc((void**)&d.inc.h_pieces, sizeof(IncPiece) * (size_t)d.inc.max_pieces, hipHostMallocDefault));
         LVI_HIP(hipHostMalloc((void**)&d.inc.h_status, sizeof(int) * 4, hipHostMallocDefault));
+        LVI_HIP(hipHostMalloc((void**)&d.inc.h_active, sizeof(int) * (size_t)std::max(d.inc.max_active, 1), hipHostMallocDefault));
     }
     LVI_HIP(hipHostMalloc((void**)&d.h_kfSeg, sizeof(LidarDev::KfSeg) * (size_t)std::max(d.kf_seg_cap, 1), hipHostMallocDefault));
     // static segment tables of the voxel plans

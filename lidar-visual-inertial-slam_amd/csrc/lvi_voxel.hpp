@@ -139,6 +139,7 @@ struct IncMap {
     int* d_nocc = nullptr;                                 // [2]
     unsigned* kfBox = nullptr;                             // [max_kf][2][8] map-frame bbox of a stored keyframe at the pose it was added with
     int* d_active = nullptr;                               // [max_active] key indices of the current list (bbox fold)
+    int* h_active = nullptr;                               // pinned staging of the same
     int max_active = 0;
     IncPiece* d_pieces = nullptr; IncPiece* h_pieces = nullptr; int max_pieces = 0;
     SortPlan sort;                                         // (idx, slot) pairs of the live voxels, 2 segments

@@ -354,6 +354,19 @@ public:
         else check(lvi_map_assemble(h_.get(), lastKeys.data(), (int32_t)lastKeys.size()), "lvi_map_assemble");
     }
 
+    // a keyframe from an earlier session (map loaded at start-up): its DS clouds go into the device store, its pose into
+    // cloudKeyPoses3D / 6D, exactly what saveKeyFramesAndFactor leaves behind for a scan it kept
+    int seedKeyFrame(const lvi_pt* cornerDS, int32_t nc, const lvi_pt* surfDS, int32_t ns, const float pose[6], double time)
+    {
+        int32_t idx = -1;
+        check(lvi_keyframe_add(h_.get(), cornerDS, nc, surfDS, ns, pose, &idx), "lvi_keyframe_add");
+        if (idx != (int32_t)cloudKeyPoses3D.size()) throw Error(LVI_ERR_STATE, "keyframe store out of step with the key poses");
+        cloudKeyPoses3D.push_back(lvi_pt{pose[3], pose[4], pose[5], (float)idx});
+        cloudKeyPoses6D.push_back(PointTypePose{pose[3], pose[4], pose[5], (float)idx, pose[0], pose[1], pose[2], time});
+        for (int k = 0; k < 6; k++) transformTobeMapped[k] = pose[k];
+        return idx;
+    }
+
     bool saveFrame() const                                                                // :1387-1412
     {
         if (cloudKeyPoses3D.empty()) return true;

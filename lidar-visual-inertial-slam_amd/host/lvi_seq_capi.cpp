@@ -123,6 +123,12 @@ int32_t lvh_seq_scan_device(lvh_seq* s, const void* d_pts, int32_t n_raw, double
         return LVI_OK;
     });
 }
+// a keyframe of an earlier session; the node's pose becomes the seeded one
+int32_t lvh_seq_seed_keyframe(lvh_seq* s, const lvi_pt* corner, int32_t nc, const lvi_pt* surf, int32_t ns, const float pose[6], double time)
+{
+    if (!s || !pose || (nc > 0 && !corner) || (ns > 0 && !surf)) { g_err = "null argument"; return LVI_ERR_INVALID_ARG; }
+    return guarded([&]() -> int32_t { return s->mo->seedKeyFrame(corner, nc, surf, ns, pose, time); });
+}
 // key indices of the last extractCloud, in fuse order
 int32_t lvh_seq_keys(lvh_seq* s, int32_t* keys, int32_t capacity, int32_t* n)
 {

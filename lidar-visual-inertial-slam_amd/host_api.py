@@ -62,6 +62,7 @@ class HostLibrary:
         scan_args = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_float, C.c_float, C.c_float, C.POINTER(SeqResult)]
         d.lvh_seq_scan.argtypes = scan_args
         d.lvh_seq_scan_device.argtypes = scan_args
+        d.lvh_seq_seed_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_double]
         d.lvh_seq_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         d.lvh_seq_keyposes.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         d.lvh_trk_create.restype = C.c_void_p
@@ -138,6 +139,12 @@ class SequentialMapper:
         ia, ro, pi, ya = (1, imu[0], imu[1], imu[2]) if imu is not None else (0, 0.0, 0.0, 0.0)
         self.hl.check(self.hl.dll.lvh_seq_scan_device(self._s, C.c_void_p(int(d_ptr)), int(n_raw), float(stamp), ia, ro, pi, ya, C.byref(r)), "lvh_seq_scan_device")
         return self._res(r)
+
+    def seed_keyframe(self, corner, surf, pose, time):
+        """a keyframe of an earlier session: DS clouds (sensor frame) into the device store, pose into the key poses"""
+        c, s = A.as_pts(corner), A.as_pts(surf)
+        pose_c = (C.c_float * 6)(*[float(v) for v in pose])
+        return self.hl.check(self.hl.dll.lvh_seq_seed_keyframe(self._s, A._ptr(c), len(c), A._ptr(s), len(s), pose_c, float(time)), "lvh_seq_seed_keyframe")
 
     def keys(self):
         n = C.c_int32(0)

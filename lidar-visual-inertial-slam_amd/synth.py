@@ -126,7 +126,7 @@ def transform_points(pts, pose):
     return out.view(A.PT_DTYPE).reshape(-1)
 
 
-def make_map(extractor, n_keyframes, n_raw, seed=4711, pose_sigma=(0.01, np.deg2rad(0.1)), torch_device=None, target_surf=None):
+def make_map(extractor, n_keyframes, n_raw, seed=4711, pose_sigma=(0.01, np.deg2rad(0.1)), torch_device=None, target_surf=None, keyframes_out=None):
     """frozen local map: laserCloud{Corner,Surf}FromMap before downsampling.
 
     `extractor` is any LidarHotpath (its organize+extract stages turn each synthetic
@@ -148,6 +148,8 @@ def make_map(extractor, n_keyframes, n_raw, seed=4711, pose_sigma=(0.01, np.deg2
         noisy = pose.copy()
         noisy[:3] += rng.normal(0, pose_sigma[1], 3)
         noisy[3:] += rng.normal(0, pose_sigma[0], 3)
+        if keyframes_out is not None:
+            keyframes_out.append((c.copy(), s.copy(), noisy.astype(np.float32)))      # sensor-frame clouds + the pose they were mapped with
         corners.append(transform_points(c, noisy))
         surfs.append(transform_points(s, noisy))
         n_surf += len(s)
