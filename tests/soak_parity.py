@@ -49,9 +49,32 @@ def sector_ties(info, curv, n_scan):
     return False
 
 
+def tied_sectors(info, curv, n_scan):
+    """[(ring, sector, sp, ep)] of the sectors that hold two equal curvature values"""
+    st, en = info["start_ring_index"], info["end_ring_index"]
+    out = []
+    for ring in range(n_scan):
+        for j in range(6):
+            sp = (int(st[ring]) * (6 - j) + int(en[ring]) * j) // 6
+            ep = (int(st[ring]) * (5 - j) + int(en[ring]) * (j + 1)) // 6 - 1
+            if sp < ep:
+                c = curv[sp:ep + 1].view(np.uint32)
+                if len(np.unique(c)) != len(c):
+                    out.append((ring, j, sp, ep))
+    return out
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
+    detail = set(int(c) for c in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    summary = run(n_cases, seed, only=detail, verbose=detail is not None)
+    print(json.dumps(summary))
+    return summary["classes"]["unexplained"]
+
+
+def run(n_cases, seed, only=None, verbose=False):
+    """execute the cases in `only` (all when None) of the seeded stream of n_cases cases; returns the summary dict"""
     pkg = graft.import_package()
     from oracle import loader
     oracle, hip = loader.load(pkg), pkg.load_hip()
@@ -61,7 +84,8 @@ def main():
     bad, worst, seam_worst, report = 0, 0.0, 0.0, []
     classes = dict(ties=0, second_ds=0, gn=0, knife=0, unexplained=0)
     t0 = time.time()
-    detail = set(int(c) for c in sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    detail = set(only) if only is not None else None
+    executed = 0
     for case in range(n_cases):
         # ---- draw the whole case first (the random stream does not depend on which cases are executed)
         n_scan = int(rng.choice([4, 4, 4, 6, 16]))
@@ -81,6 +105,7 @@ def main():
             reps.append(r)
         if detail is not None and case not in detail:
             continue
+        executed += 1
         if mseed not in scenes:
             scenes[mseed] = make_small_scene(pkg, oracle, seed=4711 + mseed)
         scene = scenes[mseed]
@@ -110,7 +135,7 @@ def main():
                     diffs.append("label/index" + (" (curvature ties in a sector)" if tied else ""))
                     kinds.add("ties" if tied else "unexplained")
                 if not np.array_equal(lo[5:n - 5], lg[5:n - 5]):
-                    if detail is not None:
+                    if verbose:
                         idx = np.nonzero(lo[5:n - 5] != lg[5:n - 5])[0] + 5
                         cu_o, cu_g = o.debug_get(A.DBG_CURVATURE, np.float32), g.debug_get(A.DBG_CURVATURE, np.float32)
                         po, pg = o.debug_get(A.DBG_PICKED_FINAL, np.int32), g.debug_get(A.DBG_PICKED_FINAL, np.int32)
@@ -126,7 +151,13 @@ def main():
             if co != cg and not deskew and "ties" not in kinds:
                 diffs.append(f"first-stage counts {co} {cg}"); kinds.add("unexplained")
             if loose > 3:
-                diffs.append(f"surf_ds±{loose}"); kinds.add("second_ds" if loose <= 12 else "unexplained")
+                # cause: the second-stage grid sees first-stage centroids that differ by the centroid tolerance.  With ONE input
+                # (the oracle's first-stage cloud) both libraries must return the same voxel set
+                s_in = o.get_features()[1]
+                leaf2 = float(kw.get("mappingSurfLeafSize", 0.4))
+                same_input_agrees = len(o.voxel_downsample(s_in, leaf2)) == len(g.voxel_downsample(s_in, leaf2))
+                diffs.append(f"surf_ds±{loose}" + ("" if same_input_agrees else " and the counts differ on identical input"))
+                kinds.add("second_ds" if loose <= 12 and same_input_agrees else "unexplained")
             ro, rg = o.scan_match(guess), g.scan_match(guess)
             # the GN path alone: the oracle's downsampled map (one point per voxel: re-voxelising it returns the same bits on
             # both sides) and the oracle's downsampled scan through the one-call seam of both libraries
@@ -136,7 +167,7 @@ def main():
             for h in (o2, g2):
                 h.map_set(mc, ms)
             so, sg = o2.scan_to_map(fc, fs, p0), g2.scan_to_map(fc, fs, p0)
-            if detail is not None:
+            if verbose:
                 jo, jg = o2.debug_get(A.DBG_ICP_JTJ, np.float32).reshape(-1, 27), g2.debug_get(A.DBG_ICP_JTJ, np.float32).reshape(-1, 27)
                 to, tg = o2.debug_get(A.DBG_ICP_POSE_TRACE, np.float32).reshape(-1, 6), g2.debug_get(A.DBG_ICP_POSE_TRACE, np.float32).reshape(-1, 6)
                 np.set_printoptions(linewidth=250, precision=9)
@@ -163,7 +194,7 @@ def main():
             elif nsel_gap:
                 diffs.append(f"identical-input GN: selected counts {so['n_sel']} vs {sg['n_sel']}, pose diff {seam_diff:.3e}")
                 kinds.add("knife")
-            if detail is not None:
+            if verbose:
                 print("pose o", ro["pose"], "iters", ro["iters"], "n_sel", ro["n_sel"]); print("pose g", rg["pose"], "iters", rg["iters"], "n_sel", rg["n_sel"])
                 print("diff  ", np.abs(ro["pose"] - rg["pose"]), "noise", r["noise"], "deskew", deskew, "n_raw", r["n_raw"], "voxel_mode", voxel_mode)
             if ro["status"] != rg["status"] or ro["iters"] != rg["iters"]:
@@ -182,8 +213,7 @@ def main():
             print("DIFF", case, kind, kw, diffs, flush=True)
         if case % 10 == 9:
             print(f"[{case + 1}/{n_cases}] differing={bad} {classes} worst_pose_diff={worst:.3e} seam_worst={seam_worst:.3e} {time.time() - t0:.0f}s", flush=True)
-    print(json.dumps(dict(cases=n_cases, seed=seed, differing=bad, classes=classes, worst_pose_diff_staged=worst, worst_pose_diff_seam=seam_worst, report=report)))
-    return classes["unexplained"]
+    return dict(cases=n_cases, executed=executed, seed=seed, differing=bad, classes=classes, worst_pose_diff_staged=worst, worst_pose_diff_seam=seam_worst, report=report)
 
 
 if __name__ == "__main__":

@@ -20,9 +20,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as graft  # noqa: E402
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 77
+def main(n_cases=None, seed=None):
+    n_cases = n_cases if n_cases is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 60)
+    seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 77)
     pkg = graft.import_package()
     from oracle import loader
     oracle, hip = loader.load(pkg), pkg.load_hip()

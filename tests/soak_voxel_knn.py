@@ -45,9 +45,9 @@ def make_cloud(rng, n):
     return pts
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 31
+def main(n_cases=None, seed=None):
+    n_cases = n_cases if n_cases is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 200)
+    seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 31)
     pkg = graft.import_package()
     from oracle import loader
     oracle, hip = loader.load(pkg), pkg.load_hip()
