@@ -27,6 +27,7 @@ int main(int argc, char** argv)
     try {
         if (argc >= 15 && !strcmp(argv[1], "lidar")) {
             lvi_lidar_params P; lvi_lidar_params_default(&P);
+            if (const char* e = getenv("LVI_NUMBER_OF_CORES")) P.numberOfCores = atoi(e);     // OpenMP threads of the CPU library (tests)
             P.Horizon_SCAN = atoi(argv[2]);
             const int n_raw = atoi(argv[4]), nc = atoi(argv[6]), ns = atoi(argv[8]);
             P.max_raw_points = n_raw + 16; P.max_map_points = std::max(nc, ns) + 16;
@@ -72,6 +73,7 @@ int main(int argc, char** argv)
             // f-1 deskew through ImageProjection::imuDeskewInfo, f-4 keyframes + map assembly + matching against it,
             // f-2 equalised readImage, f-3 undistortedPoints: the rows next to the path, through the host mirror
             lvi_lidar_params P; lvi_lidar_params_default(&P);
+            if (const char* e = getenv("LVI_NUMBER_OF_CORES")) P.numberOfCores = atoi(e);     // OpenMP threads of the CPU library (tests)
             P.Horizon_SCAN = atoi(argv[2]);
             const int n_raw = atoi(argv[4]);
             P.max_raw_points = n_raw + 16; P.max_map_points = 1 << 20;

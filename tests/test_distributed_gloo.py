@@ -83,3 +83,130 @@ def test_two_ranks_gloo(tmp_path):
     u = __import__("numpy").asarray(r0)
     assert (u[:, 6].view(np.int32) == 0).all() and (u[:, 7].view(np.int32) == 10).all()
     assert np.abs(u[:, 3:6] - truth[:, 3:6]).max() < 0.06
+
+
+ROLLING_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+import __graft_entry__ as graft
+from oracle import loader
+pkg = graft.import_package()
+R, S = pkg.replay, pkg.synth
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+lib = loader.load(pkg)
+B, NB, POOL, STEPS, DEPTH = 2, 2, 3, 5, 2                 # handles per rank, scans per launch sequence, odd step count, queue depth 2
+P = dict(N_SCAN=4, Horizon_SCAN=2048, max_raw_points=8192, max_map_points=65536, icp_max_iters=6, icp_disable_break=1, batch_scans=NB)
+hs = [pkg.LidarHotpath(lib, **P) for _ in range(B)]
+hdr = torch.zeros(2, dtype=torch.int64)
+if rank == 0:
+    mc, ms = S.make_map(hs[0], 5, 5001, seed=17)
+    hdr[0], hdr[1] = len(mc), len(ms)
+dist.broadcast(hdr, 0)
+tc = torch.zeros((int(hdr[0]), 4)); ts = torch.zeros((int(hdr[1]), 4))
+if rank == 0:
+    tc.copy_(torch.from_numpy(pkg._abi.pts_xyzi(mc))); ts.copy_(torch.from_numpy(pkg._abi.pts_xyzi(ms)))
+dist.broadcast(tc, 0); dist.broadcast(ts, 0)
+for h in hs:
+    h.map_upload(tc.numpy(), ts.numpy()); h.map_build()
+poses = [S.loop_pose(0.3 + 0.9 * (rank * POOL + k), 0.01, -0.01) for k in range(POOL)]
+scans = [S.make_scan(5001, poses[k], 100 + rank * POOL + k) for k in range(POOL)]
+guesses = [S.perturbed_guess(poses[k], rank * POOL + k) for k in range(POOL)]
+per_step = B * NB
+rec = torch.zeros((STEPS * per_step, 8), dtype=torch.float32)            # this rank's records ("device" memory of the CPU library)
+gathered = {}
+
+def issue(i, b, h):
+    ks = [R.scan_index(i, b, z, B, NB, POOL) for z in range(NB)]
+    h.batch_upload([scans[k] for k in ks])
+    base = (i * B + b) * NB
+    h.batch_run(np.stack([guesses[k] for k in ks]), rec[base].data_ptr(), rebuild_map=True)
+
+def gather(j):
+    gathered[j] = R.gather_records(rec[j * per_step:(j + 1) * per_step], world, dist).clone()
+
+roll = R.RollingReplay(hs, issue, gather, depth=DEPTH)
+for i in range(STEPS):
+    roll.step(i)
+    assert len(roll.pending) <= DEPTH
+roll.flush()
+assert roll.gathered == list(range(STEPS)), roll.gathered
+out = %(out)r
+np.save(os.path.join(out, "roll_rec_rank%%d.npy" %% rank), rec.numpy())
+np.save(os.path.join(out, "roll_gather_rank%%d.npy" %% rank), torch.stack([gathered[j] for j in range(STEPS)]).numpy())
+# the same scans one by one on a plain handle: what every record must equal
+P1 = dict(P); P1["batch_scans"] = 1
+h1 = pkg.LidarHotpath(lib, **P1)
+h1.map_upload(tc.numpy(), ts.numpy())
+ref = np.zeros((POOL, 8), np.float32)
+for k in range(POOL):
+    h1.map_build(); h1.scan_upload(scans[k]); h1.scan_organize(); h1.scan_extract(); h1.scan_downsample()
+    r = h1.scan_match(guesses[k])
+    ref[k] = R.pack_record(r["pose"], r["status"], r["iters"])
+np.save(os.path.join(out, "roll_ref_rank%%d.npy" %% rank), ref)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_rolling_batched_replay_two_ranks_gloo(pkg, tmp_path):
+    """the loop bench.py times (replay.RollingReplay: B handles, S scans per launch sequence, queue depth 2, odd step count,
+    all_gather of every step's records) under gloo with two ranks and the CPU library behind the same handle interface"""
+    port = _free_port()
+    script = tmp_path / "roll_worker.py"
+    script.write_text(ROLLING_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    R = pkg.replay
+    B, NB, POOL, STEPS = 2, 2, 3, 5
+    recs = [np.load(tmp_path / f"roll_rec_rank{r}.npy") for r in range(2)]
+    refs = [np.load(tmp_path / f"roll_ref_rank{r}.npy") for r in range(2)]
+    gath = [np.load(tmp_path / f"roll_gather_rank{r}.npy") for r in range(2)]
+    np.testing.assert_array_equal(gath[0], gath[1])                      # every rank holds every step's records of every rank
+    assert gath[0].shape == (STEPS, 2, B * NB, 8)
+    for r in range(2):
+        for i in range(STEPS):
+            for b in range(B):
+                for z in range(NB):
+                    k = R.scan_index(i, b, z, B, NB, POOL)
+                    row = recs[r][(i * B + b) * NB + z]
+                    np.testing.assert_array_equal(row, refs[r][k])       # batched, rolling, sharded: the bits of the plain path
+                    np.testing.assert_array_equal(gath[0][i, r, b * NB + z], row)
+        assert (recs[r][:, 6].view(np.int32) == 0).all() and (recs[r][:, 7].view(np.int32) == 6).all()
+
+
+def test_rolling_replay_bookkeeping(pkg):
+    """depth 0 / 1 / 3 and the frame sharding of the tracker leg, without any library"""
+    R = pkg.replay
+
+    class Fake:
+        def __init__(self):
+            self.log = []
+
+        def wait_mark(self, s): self.log.append(("wait", s))
+        def mark(self, s): self.log.append(("mark", s))
+        def sync(self): self.log.append(("sync",))
+
+    for depth in (0, 1, 3):
+        hs = [Fake(), Fake()]
+        issued, gathered = [], []
+        roll = R.RollingReplay(hs, lambda i, b, h: issued.append((i, b)), gathered.append, depth=depth)
+        for i in range(7):
+            roll.step(i)
+            assert len(roll.pending) <= max(depth, 0)
+            # a step's records are gathered only after every handle waited for that step's mark (or synchronised)
+            assert gathered == list(range(max(0, i + 1 - depth)))
+        roll.flush()
+        assert gathered == list(range(7)) and issued == [(i, b) for i in range(7) for b in range(2)]
+        if depth:
+            assert hs[0].log[:3] == [("wait", 0), ("mark", 0), ("wait", 1 % depth)]
+    assert R.shard_frames(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((R.shard_frames(40, r, 8) for r in range(8)), [])) == list(range(40))
+    assert [R.scan_index(1, 1, z, 2, 4, 8) for z in range(4)] == [4, 5, 6, 7]
