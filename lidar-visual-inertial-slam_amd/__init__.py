@@ -8,7 +8,7 @@ import it through ``__graft_entry__.import_package()`` (module name
 """
 import os
 
-from . import _abi, host_api, replay, synth  # noqa: F401
+from . import _abi, config, host_api, replay, synth  # noqa: F401
 from ._abi import Library, LviError, PT_DTYPE, LIVOX_DTYPE  # noqa: F401
 from .lidar import LidarHotpath, default_params  # noqa: F401
 from .tracker import TrackerHotpath, default_tracker_params  # noqa: F401

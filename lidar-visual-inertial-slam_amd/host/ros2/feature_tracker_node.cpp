@@ -15,6 +15,8 @@
 #include <std_msgs/msg/bool.hpp>
 
 #include "../lvi_host.hpp"
+#include "camodocal/camera_models/CameraFactory.h"
+#include "camodocal/camera_models/CataCamera.h"
 #include "parameters.h"   // the reference's readParameters(): ROW, COL, MAX_CNT, MIN_DIST, FREQ, F_THRESHOLD, EQUALIZE, CAM_NAMES (feature_tracker/src/parameters.h)
 
 static std::unique_ptr<lvi_host::TrackerHandle> handle;
@@ -67,7 +69,11 @@ int main(int argc, char** argv)
     tracker = std::make_unique<lvi_host::FeatureTracker>(*handle, ROW, COL, MAX_CNT, MIN_DIST);
     if (EQUALIZE) tracker->setEqualize(true);
     tracker->F_THRESHOLD = F_THRESHOLD;
-    tracker->setCamera(readMeiParameters(CAM_NAMES[0]));                                 // xi, k1, k2, p1, p2, gamma1, gamma2, u0, v0 of the camera yaml
+    {   // FeatureTracker::readIntrinsicParameter (feature_tracker.cpp:256-260): the MEI parameters of the camera yaml
+        auto cam = camodocal::CameraFactory::instance()->generateCameraFromYamlFile(CAM_NAMES[0]);
+        const auto& q = std::dynamic_pointer_cast<camodocal::CataCamera>(cam)->getParameters();
+        tracker->setCamera(lvi_mei_params{q.xi(), q.k1(), q.k2(), q.p1(), q.p2(), q.gamma1(), q.gamma2(), q.u0(), q.v0()});
+    }
     tracker->findFundamentalMat = [](const std::vector<lvi_host::Point2f>& a, const std::vector<lvi_host::Point2f>& b, double thr, std::vector<uint8_t>& status) {
         std::vector<cv::Point2f> ca(a.size()), cb(b.size());
         for (size_t i = 0; i < a.size(); i++) { ca[i] = cv::Point2f(a[i].x, a[i].y); cb[i] = cv::Point2f(b[i].x, b[i].y); }
