@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-tracker", action="store_true")
     ap.add_argument("--tracker-seconds", type=float, default=0.6)
+    ap.add_argument("--prime-seconds", type=float, default=0.3,
+                    help="untimed steps before the W warm-up steps, part of the set-up: measured on this runtime, one ~45 ms stall (runtime "
+                         "pool growth) lands somewhere in the first ~0.2 s of back-to-back batched launches of a fresh process")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--sequential-scans", type=int, default=48,
                     help="secondary figure (rank 0): a sequential replay — raw stream -> pose -> keyframe -> next scan — through the C++ node "
@@ -172,7 +175,8 @@ def main():
         poses.append(pose); guesses.append(S.perturbed_guess(pose, sid)); scans_host.append(sc)
         d_scans.append(torch.from_numpy(sc.view(np.uint8).reshape(-1, 20).copy()).to(dev))
     n_windows = max(1, args.repeats)
-    total = args.warmup + n_windows * args.steps + args.profile_steps
+    n_prime = 400 if args.prime_seconds > 0 else 0                    # upper bound of the priming steps (records are written, never read)
+    total = n_prime + args.warmup + n_windows * args.steps + args.profile_steps
     per_step = B * NB                                                 # scans per step and rank
     d_rec = torch.zeros((total * per_step, 8), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -217,7 +221,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    step0 = 0
+    if n_prime:
+        t_p = time.perf_counter()
+        while step0 < n_prime and time.perf_counter() - t_p < args.prime_seconds:
+            roll.step(step0); step0 += 1
+        roll.flush()
+    for i in range(step0, step0 + args.warmup):
         roll.step(i)
     roll.flush()
     fence()
@@ -226,7 +236,7 @@ def main():
     for w in range(n_windows):
         enq[0] = 0.0
         t0 = time.perf_counter()
-        first = args.warmup + w * args.steps
+        first = step0 + args.warmup + w * args.steps
         for i in range(first, first + args.steps):
             roll.step(i)
         roll.flush()
@@ -244,7 +254,7 @@ def main():
     rates = [world * per_step * args.steps / e for e in win]
 
     # ---------------------------------------------------------------- sanity of what was timed (every record of every window, vs ground truth)
-    lo, hi = args.warmup * per_step, (args.warmup + n_windows * args.steps) * per_step
+    lo, hi = (step0 + args.warmup) * per_step, (step0 + args.warmup + n_windows * args.steps) * per_step
     rec = d_rec[lo:hi].cpu().numpy()
     status = rec[:, 6].copy().view(np.int32)
     iters = rec[:, 7].copy().view(np.int32)
@@ -282,7 +292,7 @@ def main():
     stats, kern_ms = [], 0.0
     if args.profile_steps > 0:
         g.prof_reset(); g.prof_enable(True)
-        for i in range(args.warmup + n_windows * args.steps, total):
+        for i in range(step0 + args.warmup + n_windows * args.steps, step0 + args.warmup + n_windows * args.steps + args.profile_steps):
             roll.step(i)
         roll.flush()
         stats = g.prof_read()

@@ -1257,7 +1257,7 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
         // exactly the occupied 360 instead changes nothing)
         // iteration 0 searches the unit ball with 8 lanes per feature; later iterations search the (much smaller) ball of the
         // previous neighbours, where the per-lane fixed cost dominates: fewer lanes per feature (d.icp_g1)
-        const int G1 = it == 0 ? 8 : d.icp_g1;
+        const int G1 = it == 0 ? d.icp_g0 : d.icp_g1;
         const dim3 rg(d.nblk_icp, 1, S);
         if (G1 == 8) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<8, 8>), rg, dim3(512), 0, cx.stream, B));
         else if (G1 == 4) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<4, 4>), rg, dim3(256), 0, cx.stream, B));

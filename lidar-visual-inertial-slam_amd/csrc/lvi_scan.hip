@@ -390,6 +390,11 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
     // from different streams could fill every CU with waiting consumers while their producers still wait for a CU
     bool piped = a.N_SCAN * 6 <= 24;
     for (int q = 0; q < 6; q++) { int sp_, ep_; piped = piped && bounds(q, sp_, ep_); }
+    // a ring with a sector beyond the LDS-resident capacity belongs to feat_sector_big_kernel (global-memory walk)
+    for (int q = 0; q < 6; q++) {
+        const int sp_ = (sR * (6 - q) + eR * q) / 6, ep_ = (sR * (5 - q) + eR * (q + 1)) / 6 - 1;
+        if (sp_ < ep_ && ep_ - sp_ + 11 > FEAT_SEG_CAP) return;
+    }
     if (!piped && my_sec != 0) return;
     const int sec_begin = piped ? my_sec : 0, sec_end = piped ? my_sec + 1 : 6;
     prefetch(sec_begin);
@@ -656,6 +661,137 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
 #undef LVI_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// a-3 for rings whose sectors do not fit the LDS-resident kernel (more than FEAT_SEG_CAP - 11 points per sector, e.g.
+// N_SCAN = 1 with > 49 k points): the same two walks over GLOBAL memory, one workgroup per ring, sectors in order (the marks
+// of a sector simply stay in picked[] for the next one).  Slow by design — tens of block-wide passes per sector — and exact:
+//   corners  up to 40 rounds of "largest (curvature, index) among the still unpicked candidates" = the reference's walk down
+//            the sorted range (the ep slot first, :171-174)
+//   surf     the same priority-ordered maximal independent set as the LDS kernel, state kept in label[] (2 = undecided)
+// Launched only when the handle's geometry allows such a sector (host check), and a no-op for rings the LDS kernel took.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FEAT_THREADS) void feat_sector_big_kernel(Batch<FeatArgs> B_)
+{
+    const FeatArgs& a = B_.a[blockIdx.z];
+    const int ring = blockIdx.x, tid = threadIdx.x;
+    const int n = *a.d_n;
+    const int sR = a.startR[ring], eR = a.endR[ring];
+    bool big = false;
+    for (int q = 0; q < 6; q++) {
+        const int sp_ = (sR * (6 - q) + eR * q) / 6, ep_ = (sR * (5 - q) + eR * (q + 1)) / 6 - 1;
+        big = big || (sp_ < ep_ && ep_ - sp_ + 11 > FEAT_SEG_CAP);
+    }
+    if (!big) return;
+    const int fresh = *a.d_fresh;
+    volatile uint8_t* picked = a.picked;
+    volatile int8_t* label = a.label;
+    const float* __restrict__ curv = a.curv;
+    const uint8_t* __restrict__ pfl = a.pflags;                  // bit 1: column break between k-1 and k
+    __shared__ unsigned long long s_best[FEAT_THREADS / 64];
+    __shared__ int s_flag;
+    auto brk = [&](int k) { return k <= 0 || k >= n || ((pfl[k] >> 1) & 1); };      // the cloud's ends count as breaks
+    auto fwd_reach = [&](int k) { int f = 0; while (f < 5 && !brk(k + f + 1)) f++; return f; };
+    auto bwd_reach = [&](int k) { int b = 0; while (b < 5 && !brk(k - b)) b++; return b; };
+    for (int sec = 0; sec < 6; sec++) {
+        const int sp = (sR * (6 - sec) + eR * sec) / 6, ep = (sR * (5 - sec) + eR * (sec + 1)) / 6 - 1;
+        int* out_idx = a.sector_idx + (ring * 6 + sec) * CORNERS_PER_SECTOR;
+        if (sp >= ep) { if (tid == 0) a.sector_cnt[ring * 6 + sec] = 0; continue; }
+        // slot 4 of the whole cloud: the never-rewritten cloudSmoothness entry, not a candidate
+        const int klo = (sp == 4 && ring == 0 && sec == 0) ? 5 : sp;
+        // ---- corners
+        int taken = 0;
+        for (int round = 0; round < CORNERS_PER_SECTOR + 1; round++) {
+            unsigned long long best = 0ull;                       // (curvature bits << 32) | (k - sp + 1); 0 = none
+            if (round == 0) {
+                if (tid == 0 && picked[ep] == 0 && curv[ep] > a.edgeThreshold) best = ((unsigned long long)__float_as_uint(curv[ep]) << 32) | (unsigned)(ep - sp + 1);
+            } else {
+                for (int k = klo + tid; k < ep; k += FEAT_THREADS)
+                    if (picked[k] == 0 && curv[k] > a.edgeThreshold) {
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(curv[k]) << 32) | (unsigned)(k - sp + 1);
+                        best = key > best ? key : best;
+                    }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(best, o, 64); best = v > best ? v : best; }
+            if (lane_id() == 0) s_best[wave_id()] = best;
+            __syncthreads();
+            best = 0ull;
+            for (int w = 0; w < FEAT_THREADS / 64; w++) best = s_best[w] > best ? s_best[w] : best;
+            __syncthreads();
+            if (best == 0ull) { if (round == 0) continue; break; }
+            const int win = sp + (int)(unsigned)(best & 0xFFFFFFFFull) - 1;
+            if (tid == 0) {
+                out_idx[taken] = win; label[win] = 1; picked[win] = 1;
+                const int f = fwd_reach(win), b = bwd_reach(win);
+                for (int q = 1; q <= f; q++) picked[win + q] = 1;
+                for (int q = 1; q <= b; q++) picked[win - q] = 1;
+            }
+            taken++;
+            __threadfence_block();
+            __syncthreads();
+            if (taken >= CORNERS_PER_SECTOR) break;
+        }
+        if (tid == 0) a.sector_cnt[ring * 6 + sec] = taken;
+        // ---- first scan of a fresh node (see the LDS kernel)
+        if (klo == 5 && fresh && tid == 0) {
+            bool ok = true;
+            for (int k = 1; k <= 5; k++) ok = ok && (abs(a.col[k] - a.col[k - 1]) <= 10);
+            if (ok && a.surfThreshold > 0.f) picked[5] = 1;
+            if (a.surfThreshold > 0.f && n > 0) { label[0] = -1; picked[0] = 1; }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- surf walk: candidates = unpicked points below the threshold; order = ascending (curvature, index), ep last
+        for (int k = klo + tid; k <= ep; k += FEAT_THREADS)
+            if (picked[k] == 0 && curv[k] < a.surfThreshold && label[k] == 0) label[k] = 2;
+        __threadfence_block();
+        __syncthreads();
+        auto earlier = [&](int q, int k) {                        // does q come before k in the walk?
+            if (q == ep) return false;
+            if (k == ep) return true;
+            const float cq = curv[q], ck = curv[k];
+            return cq < ck || (cq == ck && q < k);
+        };
+        for (int it = 0; it < n + 2; it++) {
+            if (tid == 0) s_flag = 0;
+            __syncthreads();
+            for (int k = klo + tid; k <= ep; k += FEAT_THREADS) {
+                if (label[k] != 2) continue;
+                bool blocked = false, wait = false;
+                const int f = fwd_reach(k), b = bwd_reach(k);
+                for (int q = 1; q <= f && k + q <= ep; q++) {
+                    const int8_t lq = label[k + q];
+                    if ((lq == -1 || lq == 2) && earlier(k + q, k)) { blocked = blocked || lq == -1; wait = wait || lq == 2; }
+                }
+                for (int q = 1; q <= b && k - q >= klo; q++) {
+                    const int8_t lq = label[k - q];
+                    if ((lq == -1 || lq == 2) && earlier(k - q, k)) { blocked = blocked || lq == -1; wait = wait || lq == 2; }
+                }
+                // decisions are monotone: reading a neighbour's old or new state gives a valid (possibly later) decision
+                if (blocked) label[k] = 0;
+                else if (!wait) label[k] = -1;
+                else s_flag = 1;
+            }
+            __threadfence_block();
+            __syncthreads();
+            const int any = s_flag;
+            __syncthreads();
+            if (!any) break;
+        }
+        // ---- marks of the labelled points, then the surf candidates of the sector (:231-236)
+        for (int k = klo + tid; k <= ep; k += FEAT_THREADS)
+            if (label[k] == -1) {
+                picked[k] = 1;
+                const int f = fwd_reach(k), b = bwd_reach(k);
+                for (int q = 1; q <= f; q++) picked[k + q] = 1;
+                for (int q = 1; q <= b; q++) picked[k - q] = 1;
+            }
+        for (int k = sp + tid; k <= ep; k += FEAT_THREADS) a.surfmask[k] = (label[k] <= 0) ? 1 : 0;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // corners in output order (ring, sector, pick order) + segment descriptors of the per-ring VoxelGrid
 __global__ void feat_finalize_kernel(Batch<FeatArgs> B_)
 {
@@ -779,6 +915,7 @@ void lidar_allocate(LidarDev& d)
     d.max_cells = (int)std::min<long long>(1ll << 24, std::max<long long>(1ll << 18, 4ll * d.map_cap));
     { const char* e = getenv("LVI_KNN_NO_BOUND"); d.knn_bound = !(e && e[0] == '1'); }
     { const char* e = getenv("LVI_VB_BINS"); if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && b <= VB_NB) { d.voxMap.bin_pts = a; d.voxMap.bin_max = b; } } }
+    { const char* e = getenv("LVI_ICP_G0"); if (e) d.icp_g0 = atoi(e); }
     { const char* e = getenv("LVI_ICP_G1"); if (e) d.icp_g1 = atoi(e); if (!d.knn_bound) d.icp_g1 = 8; }
     d.feat_handover_ticks = d.P.sector_handover_wait_us < 0 ? 0 : 100ll * (d.P.sector_handover_wait_us > 0 ? d.P.sector_handover_wait_us : 2000);
     d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / KNN_G);
@@ -848,6 +985,11 @@ void stage_extract(const Slots& sl)
     const Ctx& cx = d.ctx;
     LVI_LAUNCH(cx, "feat_smooth", 8.0 * n + 8.0 * n, hipLaunchKernelGGL(feat_smooth_kernel, dim3(div_up(d.ext_cap, 256), 1, sl.n), dim3(256), 0, cx.stream, B));
     LVI_LAUNCH(cx, "feat_sector", 8.0 * n, hipLaunchKernelGGL(feat_sector_kernel, dim3(d.P.N_SCAN * 6, 1, sl.n), dim3(FEAT_THREADS), 0, cx.stream, B));
+    // sectors beyond the LDS-resident capacity: possible only when a ring may hold more than 6 (FEAT_SEG_CAP - 11) points
+    int n_max = 0;
+    for (int z = 0; z < sl.n; z++) n_max = std::max(n_max, sl[z].n_raw);
+    if (std::min(d.P.Horizon_SCAN, n_max) / 6 + 12 > FEAT_SEG_CAP)
+        LVI_LAUNCH(cx, "feat_sector_big", 8.0 * n, hipLaunchKernelGGL(feat_sector_big_kernel, dim3(d.P.N_SCAN, 1, sl.n), dim3(FEAT_THREADS), 0, cx.stream, B));
     LVI_LAUNCH(cx, "feat_finalize", 0, hipLaunchKernelGGL(feat_finalize_kernel, dim3(1, 1, sl.n), dim3(256), 0, cx.stream, B));
     voxel_downsample_batch(cx, plans, sl.n, "ring", n);
 }

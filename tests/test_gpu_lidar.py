@@ -758,23 +758,32 @@ def test_many_handles_in_flight(pkg, hip, scene):
         h.close()
 
 
-def test_device_error_reaches_the_async_record(pkg, hip, scene):
-    """a device-side error of a producer stage (here: a ring sector beyond the LDS-resident capacity) is carried by the
-    32-byte record of the async / replay path, not only by the host-fetch entry points"""
-    A = pkg._abi
-    S = pkg.synth
-    P = dict(N_SCAN=1, Horizon_SCAN=65536, max_raw_points=70000, max_map_points=400000, icp_max_iters=3, icp_disable_break=1)
-    g = pkg.LidarHotpath(hip, **P)
-    g.map_upload(scene["map_corner"], scene["map_surf"]); g.map_build()
-    scan = S.make_scan(60001, S.loop_pose(0.37, 0.01, -0.02), 5)
-    scan["line"] = 0                                            # one ring of 60 000 points: sectors of 10 000 > FEAT_SEG_CAP
-    g.scan_upload(scan); g.scan_organize(); g.scan_extract(); g.scan_downsample()
-    g.scan_match_async(scene["guess"], 0)
-    rec = np.zeros(8, np.float32)
-    code = hip.dll.lvi_get_pose_record(g._h, A._ptr(rec))       # fills the record, then reports the device status word
-    assert code == A.LVI_ERR_CAPACITY
-    assert int(rec[6:7].view(np.int32)[0]) == A.LVI_ERR_CAPACITY
-    g.close()
+def test_oversize_sectors_take_the_global_memory_walk(pkg, oracle, hip, scene):
+    """N_SCAN = 1 with 60 000 points: sectors of 10 000 points exceed the LDS-resident sector kernel (FEAT_SEG_CAP = 8 192); such
+    rings go through feat_sector_big_kernel (same two walks over global memory).  Indices, labels, picked flags and the whole
+    path as the oracle; a mixed scan (one oversize ring next to ordinary ones) too"""
+    A, S = pkg._abi, pkg.synth
+    for n_scan, lines in ((1, lambda sc: 0), (3, lambda sc: np.where(np.arange(len(sc)) % 10 < 8, 0, 1 + np.arange(len(sc)) % 2))):
+        P = dict(N_SCAN=n_scan, Horizon_SCAN=65536, max_raw_points=70000, max_map_points=400000)
+        o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P)
+        for h in (o, g):
+            h.map_set(scene["map_corner"], scene["map_surf"])
+        for rep in range(2):                                        # fresh handle, then reused
+            pose = S.loop_pose(0.37 + 0.3 * rep, 0.01, -0.02)
+            scan = S.make_scan(60001, pose, 5 + rep)
+            scan["line"] = lines(scan)
+            for h in (o, g):
+                h.scan_upload(scan); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+            n = o.counts()["n"]
+            np.testing.assert_array_equal(o.debug_get(A.DBG_CORNER_INDEX, np.int32), g.debug_get(A.DBG_CORNER_INDEX, np.int32))
+            np.testing.assert_array_equal(o.debug_get(A.DBG_LABEL, np.int32)[5:n - 5], g.debug_get(A.DBG_LABEL, np.int32)[5:n - 5])
+            np.testing.assert_array_equal(o.debug_get(A.DBG_PICKED_FINAL, np.int32)[5:n - 6], g.debug_get(A.DBG_PICKED_FINAL, np.int32)[5:n - 6])
+            co, cg = o.counts(), g.counts()
+            assert abs(co.pop("surf_ds") - cg.pop("surf_ds")) <= 3 and co == cg, (co, cg)
+            ro, rg = o.scan_match(S.perturbed_guess(pose, rep)), g.scan_match(S.perturbed_guess(pose, rep))
+            assert ro["status"] == rg["status"] == 0 and ro["iters"] == rg["iters"]
+            assert np.abs(ro["pose"] - rg["pose"]).max() < 1e-4
+        o.close(); g.close()
 
 
 # ----------------------------------------------------------------------------- batched launches

@@ -19,7 +19,7 @@ pose = S.loop_pose(0.37, 0.0, -0.02)
 scan = S.make_scan(100001, pose, 12345)
 guess = S.perturbed_guess(pose, 0)
 names = ["pose", "knn_total", "merge", "residual", "reduce", "total", "row_setup", "first_batch", "s_part", "s_comb", "s_solve", "s_pose", "s_total", "T", "bounded", ""]
-for nb, g1 in (("1", "8"), ("0", "8"), ("0", "84"), ("0", "4"), ("0", "2")):
+for nb, g1 in (("0", os.environ.get("LVI_ICP_G1", "4")),):
     os.environ["LVI_ICP_G1"] = g1
     os.environ["LVI_KNN_NO_BOUND"] = nb
     g = pkg.LidarHotpath(hip, **P)

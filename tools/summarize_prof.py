@@ -61,7 +61,7 @@ def steady(d, out, nsteps):
     agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
     for r in seg:
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        k = f'{short(r["Kernel_Name"])} [grid {r["Grid_Size_X"]}x{r["Grid_Size_Y"]}, wg {r["Workgroup_Size_X"]}]'
+        k = f'{short(r["Kernel_Name"])} [grid {r["Grid_Size_X"]}x{r["Grid_Size_Y"]}x{r.get("Grid_Size_Z", "1")}, wg {r["Workgroup_Size_X"]}]'
         a = agg[k]; a[0] += 1; a[1] += dur; a[2] = min(a[2], dur); a[3] = max(a[3], dur)
     total = sum(v[1] for v in agg.values())
     # union of the kernel intervals = time with at least one kernel resident (the rest is launch gaps / idle)
