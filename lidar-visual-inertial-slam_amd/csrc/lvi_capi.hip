@@ -195,7 +195,7 @@ int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** 
     h->slots.push_back(&h->d);
     h->d.P = *p; h->d.device = device;
     const int S = std::max(p->batch_scans, 1);
-    if (S > 1) h->d.P.map_on_main_stream = 1;      // a batch fills the chip by itself; one stream keeps every slot's work in one order
+    if (S > 1 && !getenv("LVI_BATCH_TWO_STREAMS")) h->d.P.map_on_main_stream = 1;      // a batch fills the chip by itself; one stream keeps every slot's work in one order
     int32_t st = guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         LVI_HIP(hipStreamCreateWithFlags(&d.ctx.stream, hipStreamNonBlocking));

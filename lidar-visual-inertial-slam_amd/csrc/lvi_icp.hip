@@ -219,8 +219,6 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
     for (int k = 0; k < 5; k++) r.k[k] = KNN_EMPTY;
     if (m.ok && m.n > 0) {
         const float e = (float)m.edge, inv_e = (float)m.inv_edge;
-        // a neighbour within sqrt(r2max) <= edge is at most one cell away on every axis (0.5 m cells: r2max < 0.24)
-        const int R = (m.R == 2 && r2max < 0.24f) ? 1 : m.R, W = 2 * R + 1, nrows = W * W;
         // cell of the query (double, as cell_of) and its position inside that cell in [0,1) (f32 is plenty: the row
         // tests below only have to be conservative, and they carry a 1e-4 margin)
         const double gx = ((double)qx - m.origin[0]) * m.inv_edge, gy = ((double)qy - m.origin[1]) * m.inv_edge, gz = ((double)qz - m.origin[2]) * m.inv_edge;
@@ -229,14 +227,22 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         // far outside the grid nothing can be within 1 m (2 cells of padding): clamp so that the ints below cannot overflow
         const int cx = (int)fmin(fmax(fxd, -4.0), (double)m.dim[0] + 4.0), cy = (int)fmin(fmax(fyd, -4.0), (double)m.dim[1] + 4.0),
                   cz = (int)fmin(fmax(fzd, -4.0), (double)m.dim[2] + 4.0);
+        // rows (y, z) of the cell block the ball of radius sqrt(r2max) reaches: the bounding rectangle of the ball in cells,
+        // never beyond the m.R cells a 1 m ball needs (2 for 0.5 m cells): at most 5 x 5 rows, 3 x 3 or fewer for the ~0.4 m
+        // balls of the bounded iterations
+        const float rc = sqrtf(r2max + 1e-4f) * inv_e + 1e-4f;
+        const int y0 = max((int)floorf(ty - rc), -m.R), y1 = min((int)floorf(ty + rc), m.R);
+        const int z0 = max((int)floorf(tz - rc), -m.R), z1 = min((int)floorf(tz + rc), m.R);
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        const int inv_ny = ny == 1 ? 256 : (ny == 2 ? 128 : (ny == 3 ? 86 : (ny == 4 ? 64 : 52)));      // (rr * inv_ny) >> 8 == rr / ny for rr < 25
         int off[KNN_RPL], st[KNN_RPL + 1];
         st[0] = 0;
 #pragma unroll
         for (int t = 0; t < KNN_RPL; t++) {
             const int rr = sub + G * t;
             int rb = 0, len = 0;
-            const int rq = W == 3 ? rr / 3 : rr / 5;                   // W is 3 or 5: constant divisors
-            const int dy = rr - rq * W - R, dz = rq - R;
+            const int rq = (rr * inv_ny) >> 8;
+            const int dy = y0 + rr - rq * ny, dz = z0 + rq;
             const int y = cy + dy, z = cz + dz;
             if (rr < nrows && y >= 0 && y < m.dim[1] && z >= 0 && z < m.dim[2]) {
                 // distance (m) from the query to the row's slab along y and z; 0 inside

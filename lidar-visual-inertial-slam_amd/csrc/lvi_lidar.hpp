@@ -105,7 +105,7 @@ struct LidarDev {
     double* icpPartial = nullptr;                          // [nblk_icp][28]
     lvi_pt* coeff = nullptr; uint8_t* flag = nullptr;      // [ext_cap] corner queries first, then surf
     int* nnPrev = nullptr;                                 // [ext_cap][5] neighbours found by the previous GN iteration
-    int icp_g0 = 8;                                        // lanes per feature in GN iteration 0 (whole unit ball; LVI_ICP_G0)
+    int icp_g0 = 4;                                        // lanes per feature in GN iteration 0 (whole unit ball; LVI_ICP_G0; measured with 16 scans in flight: 8 lanes 5 030, 4 lanes 5 245 scans/s)
     int icp_g1 = 4;                                        // lanes per feature in GN iterations >= 1 (LVI_ICP_G1 = 8 | 4 | 2 | 84 (8 lanes, batches of 4))
     bool knn_bound = true;                                 // LVI_KNN_NO_BOUND=1 at create: every iteration searches the whole unit ball (tests: same bits)
     int nblk_icp = 0;

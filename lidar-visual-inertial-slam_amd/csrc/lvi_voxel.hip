@@ -1136,7 +1136,9 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
         LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg, 1, S), dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, B));
-        const dim3 ga(std::max(256, std::min(2 * div_up(p.seg_cap, VB_CH), 2048)), p.nseg, S);      // grid-stride over the chunks
+        // grid-stride over the chunks: at most ceil(n / VB_CH) + bins of them exist; a small plan (ring / scan grids: 64 bins) gets
+        // a small grid — every workgroup of this kernel owns 40 KB of LDS, and thousands of idle ones cost 40 us of dispatch
+        const dim3 ga(std::max(64, std::min(2 * div_up(p.seg_cap, VB_CH) + 64, 2048)), p.nseg, S);
         LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel, ga, dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, gb, dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[11], 0, hipLaunchKernelGGL(vb_outscan_kernel, dim3(1, 1, S), dim3(256), 0, ctx.stream, B));
