@@ -1052,7 +1052,7 @@ void stage_map_build(const Slots& sl)
     }
     // bbox of the raw map: one pass when the map was (re)written, not one per re-voxelisation (PCL's getMinMax3D is a pure
     // function of the unchanged input)
-    if (!d.voxMap.bbox_cached) {
+    if (!d.voxMap.bbox_cached || (!d.voxMap.hist_cached && voxel_resolve_mode(d.voxMap) == VOX_BINNED)) {      // (AUTO: the first build of a plan is sorted)
         d.voxMap.n_host[0] = d.n_map_corner; d.voxMap.n_host[1] = d.n_map_surf; d.voxMap.use_n_host = true;
         voxel_bbox_pass(cx, d.voxMap, "map", (double)d.n_map_corner + (double)d.n_map_surf);
         d.voxMap.bbox_cached = true;
@@ -1063,7 +1063,7 @@ void stage_map_build(const Slots& sl)
         LidarDev& q = sl[z];
         q.n_map_corner = d.n_map_corner; q.n_map_surf = d.n_map_surf;
         q.voxMap.n_host[0] = d.n_map_corner; q.voxMap.n_host[1] = d.n_map_surf; q.voxMap.use_n_host = true;       // instead of a 1-thread launch writing d_dyn
-        q.voxMap.bbox_cached = true;
+        q.voxMap.bbox_cached = true; q.voxMap.hist_cached = d.voxMap.hist_cached;
         plans[z] = &q.voxMap;
         q.have_map = true;
     }

@@ -37,6 +37,8 @@ struct VoxArgs {
     int n_host[4]; int use_n_host;                     // host-known segment lengths (raw map), else dyn[].n
     const int* n_dev[4];                               // producer's device counters (scan grids), else dyn[].n
     int bin_pts, bin_max;                              // binned path: aim at bin_pts points per bin, at most bin_max bins
+    const unsigned* binCountCached;                    // [nseg][VB_NB] per-bin point counts of an UNCHANGED input (bbox_cached plans): vb_hist is skipped
+    unsigned* wprefix;                                 // [nseg][VB_WG][VB_NB] points of bin b in the ranges of workgroups < w (deterministic partition)
 };
 
 __device__ __forceinline__ int seg_len(const VoxArgs& a, int s)
@@ -461,6 +463,108 @@ __global__ __launch_bounds__(256) void vb_hist_kernel(Batch<VoxArgs> B_)
     for (int b = threadIdx.x; b < nbins; b += 256) { const unsigned c = cnt[b]; if (c) atomicAdd(&gc[(size_t)b * VB_PAD], c); }
 }
 
+// ---- deterministic partition (plans that cache: the raw local map) ------------------------------------------------------
+// The reservation scheme above lets ~1 200 workgroups append 21-point pieces to the advancing ends of the bins: nearly every
+// 128-byte line of the bucketed array is shared between workgroups, which is what the 55 us of vb_scatter/map are (DESIGN §9
+// of round 1).  Here workgroup w owns the contiguous point range [w K, (w+1) K) (K = a few 4 096-point tiles, VB_WG
+// workgroups at most), the per-(workgroup, bin) counts are taken once where the map is written (vb_hist_w + vb_colscan:
+// they depend on the input alone), and the scatter places workgroup w's points of bin b at binStart[b] + prefix[w][b]:
+// every workgroup writes ONE contiguous piece per bin (~80 points), filled tile after tile by the same workgroup — lines are
+// shared only at the piece ends — with no global atomics at all.
+__device__ __forceinline__ int vb_wg_points(int n) { const int k = (n + VB_STILE * VB_WG - 1) / (VB_STILE * VB_WG); return VB_STILE * max(k, 1); }
+
+__global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
+{
+    const VoxArgs& a = B_.a[blockIdx.z];
+    const int s = blockIdx.y, w = blockIdx.x;
+    const int n = a.d_n[s];
+    const VoxGrid& g = a.grid[s];
+    __shared__ unsigned cnt[VB_NB];
+    const int nbins = g.nbins, sh = g.bin_shift;
+    for (int b = threadIdx.x; b < nbins; b += 256) cnt[b] = 0u;
+    __syncthreads();
+    const int K = vb_wg_points(n);
+    const int i0 = w * K, i1 = min(n, i0 + K);
+    const int off = a.dyn[s].in_off;
+    const lvi_pt* __restrict__ in = a.st[s].in + off;
+    const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+    for (int base = i0; base < i1; base += VB_STILE) {
+#pragma unroll 4
+        for (int u = 0; u < VB_STILE / 256; u++) {
+            const int i = base + u * 256 + threadIdx.x;
+            if (i < i1 && (!mask || mask[i])) atomicAdd(&cnt[vox_key_of_pt(g, in[i]) >> sh], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_NB;
+    for (int b = threadIdx.x; b < nbins; b += 256) row[b] = cnt[b];
+}
+
+// per bin: exclusive prefix over the workgroups (in place) and the bin's total
+__global__ __launch_bounds__(256) void vb_colscan_kernel(Batch<VoxArgs> B_, unsigned* totals)
+{
+    const VoxArgs& a = B_.a[0];
+    const int s = blockIdx.y;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= VB_NB) return;
+    unsigned acc = 0u;
+    if (b < a.grid[s].nbins) {
+        unsigned* col = a.wprefix + (size_t)s * VB_WG * VB_NB + b;
+        for (int w0 = 0; w0 < VB_WG; w0 += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = col[(size_t)(w0 + u) * VB_NB];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { col[(size_t)(w0 + u) * VB_NB] = acc; acc += v[u]; }
+        }
+    }
+    totals[(size_t)s * VB_NB + b] = acc;
+}
+
+__global__ __launch_bounds__(256) void vb_scatter_det_kernel(Batch<VoxArgs> B_)
+{
+    const VoxArgs& a = B_.a[blockIdx.z];
+    const int s = blockIdx.y, w = blockIdx.x;
+    const int n = a.d_n[s];
+    const VoxGrid& g = a.grid[s];
+    const int K = vb_wg_points(n);
+    const int i0 = w * K, i1 = min(n, i0 + K);
+    if (i0 >= i1 || g.nbins == 0) return;
+    __shared__ unsigned cnt[VB_NB], pos[VB_NB];
+    const int nbins = g.nbins, sh = g.bin_shift;
+    const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
+    const unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_NB;
+    for (int b = threadIdx.x; b < nbins; b += 256) { cnt[b] = 0u; pos[b] = (unsigned)bs[b] + row[b]; }
+    __syncthreads();
+    const int off = a.dyn[s].in_off;
+    const lvi_pt* __restrict__ in = a.st[s].in + off;
+    const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+    lvi_pt* __restrict__ dst = a.bucketed + (size_t)s * a.seg_cap;
+    constexpr int IT = VB_STILE / 256;
+    for (int base = i0; base < i1; base += VB_STILE) {
+        lvi_pt p[IT]; int bin[IT]; unsigned rk[IT];
+#pragma unroll
+        for (int u = 0; u < IT; u++) {
+            const int i = base + u * 256 + threadIdx.x;
+            bin[u] = -1;
+            if (i < i1 && (!mask || mask[i])) { p[u] = in[i]; bin[u] = (int)(vox_key_of_pt(g, p[u]) >> sh); }
+        }
+#pragma unroll
+        for (int u = 0; u < IT; u++) {
+            const WaveRun r = wave_runs((unsigned)bin[u]);
+            unsigned b0 = 0u;
+            if (bin[u] >= 0 && r.head) b0 = atomicAdd(&cnt[bin[u]], (unsigned)r.len);
+            rk[u] = __shfl(b0, r.hpos, 64) + (unsigned)(lane_id() - r.hpos);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < IT; u++) if (bin[u] >= 0) dst[pos[bin[u]] + rk[u]] = p[u];
+        __syncthreads();
+        for (int b = threadIdx.x; b < nbins; b += 256) { pos[b] += cnt[b]; cnt[b] = 0u; }
+        __syncthreads();
+    }
+}
+
 // per segment: binStart = exclusive scan of binCount, cursor = binStart, binCount back to zero
 __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
 {
@@ -477,7 +581,7 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         const int b = threadIdx.x * PER + j;
-        v[j] = b < nbins ? (int)gc[(size_t)b * VB_PAD] : 0;
+        v[j] = b < nbins ? (int)(a.binCountCached ? a.binCountCached[(size_t)s * VB_NB + b] : gc[(size_t)b * VB_PAD]) : 0;
         sum += v[j];
         const int nch = wide ? (v[j] > 0) : (v[j] + VB_CH - 1) / VB_CH;
         csum += nch; msum += nch > 1 ? nch : 0;
@@ -491,7 +595,7 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         const int b = threadIdx.x * PER + j;
-        if (b < nbins) { bs[b] = ex; cur[(size_t)b * VB_PAD] = (unsigned)ex; gc[(size_t)b * VB_PAD] = 0u; cs[b] = cex; ms[b] = mex; a.binVox[(size_t)s * VB_NB + b] = 0; }
+        if (b < nbins) { bs[b] = ex; cur[(size_t)b * VB_PAD] = (unsigned)ex; if (!a.binCountCached) gc[(size_t)b * VB_PAD] = 0u; cs[b] = cex; ms[b] = mex; a.binVox[(size_t)s * VB_NB + b] = 0; }
         ex += v[j];
         const int nch = wide ? (v[j] > 0) : (v[j] + VB_CH - 1) / VB_CH;
         for (int q = 0; q < nch; q++) a.chunkBin[(size_t)s * a.max_chunks + cex + q] = b;
@@ -791,7 +895,7 @@ static VoxArgs make_args(const VoxelPlan& p)
                    p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
                    p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
                    {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0,
-                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max};
+                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max, (p.bbox_cached && p.hist_cached) ? p.d_binCountCached : nullptr, p.d_wprefix};
 }
 
 void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs)
@@ -1069,14 +1173,25 @@ void incmap_emit(const Ctx& ctx, const IncMap& m, int n_active, const float leaf
     LVI_LAUNCH(ctx, "inc_out", 0, hipLaunchKernelGGL(inc_out_kernel, gk, dim3(256), 0, ctx.stream, a));
 }
 
+// What depends on the plan's INPUT alone and is produced where the input is written (upload / assembly) instead of once per
+// re-voxelisation: the bbox partial records and — the grid geometry following from the bbox — the points per bin.
 void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
 {
     Batch<VoxArgs> B;
     B.a[0] = make_args(p);
+    B.a[0].binCountCached = nullptr;
     for (int z = 1; z < MAX_BATCH; z++) B.a[z] = B.a[0];
-    char nm[48];
-    snprintf(nm, sizeof(nm), "vox_minmax/%s", tag);
-    LVI_LAUNCH(ctx, nm, 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, 1), dim3(256), 0, ctx.stream, B));
+    char nm[3][48];
+    snprintf(nm[0], sizeof(nm[0]), "vox_minmax/%s", tag); snprintf(nm[1], sizeof(nm[1]), "vox_setup/%s", tag); snprintf(nm[2], sizeof(nm[2]), "vb_hist/%s", tag);
+    LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, 1), dim3(256), 0, ctx.stream, B));
+    p.hist_cached = false;
+    if (voxel_resolve_mode(p) == VOX_BINNED && p.d_binCountCached) {
+        LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, 1), dim3(64), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[2], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_w_kernel, dim3(VB_WG, p.nseg, 1), dim3(256), 0, ctx.stream, B));
+        hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 256, p.nseg), dim3(256), 0, ctx.stream, B, p.d_binCountCached);
+        LVI_HIP(hipGetLastError());
+        p.hist_cached = true;
+    }
 }
 
 int voxel_resolve_mode(const VoxelPlan& p)
@@ -1133,9 +1248,15 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
         const dim3 gt(div_up(p.seg_cap, VB_STILE), p.nseg, S);
         const dim3 gb(std::max(64, std::min(div_up(p.seg_cap, 2048), VB_ACC_BLOCKS)), p.nseg, S);       // grid-stride over the bins
         const dim3 gh2(std::min(div_up(p.seg_cap, VB_TILE), 512), p.nseg, S);
-        LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, B));
+        bool hist_cached = true;
+        for (int z = 0; z < S; z++) hist_cached = hist_cached && B.a[z].binCountCached != nullptr;
+        if (!hist_cached) {
+            for (int z = 0; z < S; z++) B.a[z].binCountCached = nullptr;                  // all slots the same way
+            LVI_LAUNCH(ctx, nm[7], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_kernel, gh2, dim3(256), 0, ctx.stream, B));
+        }
         LVI_LAUNCH(ctx, nm[8], 0, hipLaunchKernelGGL(vb_scan_kernel, dim3(p.nseg, 1, S), dim3(256), 0, ctx.stream, B));
-        LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, B));
+        if (hist_cached) LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_det_kernel, dim3(VB_WG, p.nseg, S), dim3(256), 0, ctx.stream, B));
+        else LVI_LAUNCH(ctx, nm[9], 32.0 * n_hint, hipLaunchKernelGGL(vb_scatter_kernel, gt, dim3(256), 0, ctx.stream, B));
         // grid-stride over the chunks: at most ceil(n / VB_CH) + bins of them exist; a small plan (ring / scan grids: 64 bins) gets
         // a small grid — every workgroup of this kernel owns 40 KB of LDS, and thousands of idle ones cost 40 us of dispatch
         const dim3 ga(std::max(64, std::min(2 * div_up(p.seg_cap, VB_CH) + 64, 2048)), p.nseg, S);

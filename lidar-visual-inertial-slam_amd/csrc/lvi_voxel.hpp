@@ -43,6 +43,7 @@ constexpr int VB_CL_LOG = 10;    // binned path: voxels accumulated in LDS per s
 constexpr int VB_TILE = 4096;    // binned path: points per tile of the histogram kernel (grid-stride)
 constexpr int VB_STILE = 4096;   // binned path: points per workgroup of the scatter kernel (2048: 62 us instead of 56 us for the 4.9 M-point map)
 constexpr int VB_PAD = 1;        // binned path: stride of the global bin counters / cursors (one per 64-B line, VB_PAD = 16, measured SLOWER: hist 36 vs 29 us, scatter 67 vs 56 us)
+constexpr int VB_WG = 512;       // deterministic partition: workgroups (= contiguous point ranges) per segment (256 / 512 / 1024: scatter 62 / 44 / 46 us on the 4.87 M-point map)
 constexpr int VB_CH = 4096;      // binned path: points per accumulate workgroup (chunk of a bin)
 constexpr int VB_ACC_BLOCKS = 1024;
 enum VoxMode { VOX_AUTO = 0, VOX_SORTED = 1, VOX_BINNED = 2 };
@@ -84,6 +85,9 @@ struct VoxelPlan {
     unsigned long long* h_ncells = nullptr;   // pinned host, [nseg]: div_b product of the latest run (AUTO's hint)
     mutable int last_mode = VOX_SORTED;       // what the latest voxel_downsample_batch enqueued
     int bin_pts = 2048, bin_max = 1024;       // binned path: points aimed at per bin, most bins (<= VB_NB)
+    unsigned* d_wprefix = nullptr;            // [nseg][VB_WG][VB_NB] per-(workgroup, bin) prefix of the deterministic partition, plans that cache only
+    unsigned* d_binCountCached = nullptr;     // [nseg][VB_NB] points per bin of the current input (voxel_bbox_pass), plans that cache only
+    mutable bool hist_cached = false;         // … valid (binned realisation was the resolved one when the pass ran)
     bool bbox_cached = false;                 // d_mmPartial holds the bbox partials of the CURRENT input (voxel_bbox_pass ran after the input was written)
 
     template <class AR> void allocate(AR& ar, int nseg_, int seg_cap_, bool concat)
