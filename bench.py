@@ -65,9 +65,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-tracker", action="store_true")
     ap.add_argument("--tracker-seconds", type=float, default=0.6)
-    ap.add_argument("--prime-seconds", type=float, default=0.3,
+    ap.add_argument("--prime-steps", type=int, default=80,
                     help="untimed steps before the W warm-up steps, part of the set-up: measured on this runtime, one ~45 ms stall (runtime "
-                         "pool growth) lands somewhere in the first ~0.2 s of back-to-back batched launches of a fresh process")
+                         "pool growth) lands somewhere in the first ~0.2 s of back-to-back batched launches of a fresh process.  A COUNT, "
+                         "not a duration: every rank must issue the same number of per-step collectives")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--sequential-scans", type=int, default=48,
                     help="secondary figure (rank 0): a sequential replay — raw stream -> pose -> keyframe -> next scan — through the C++ node "
@@ -175,7 +176,7 @@ def main():
         poses.append(pose); guesses.append(S.perturbed_guess(pose, sid)); scans_host.append(sc)
         d_scans.append(torch.from_numpy(sc.view(np.uint8).reshape(-1, 20).copy()).to(dev))
     n_windows = max(1, args.repeats)
-    n_prime = 400 if args.prime_seconds > 0 else 0                    # upper bound of the priming steps (records are written, never read)
+    n_prime = max(0, args.prime_steps)                                # priming steps (records are written, never read)
     total = n_prime + args.warmup + n_windows * args.steps + args.profile_steps
     per_step = B * NB                                                 # scans per step and rank
     d_rec = torch.zeros((total * per_step, 8), dtype=torch.float32, device=dev)
@@ -223,9 +224,9 @@ def main():
 
     step0 = 0
     if n_prime:
-        t_p = time.perf_counter()
-        while step0 < n_prime and time.perf_counter() - t_p < args.prime_seconds:
-            roll.step(step0); step0 += 1
+        for step0 in range(n_prime):
+            roll.step(step0)
+        step0 = n_prime
         roll.flush()
     for i in range(step0, step0 + args.warmup):
         roll.step(i)

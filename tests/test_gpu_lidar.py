@@ -894,3 +894,37 @@ def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
             continue
         for x, y in zip(ra, rb):
             np.testing.assert_array_equal(x, y)
+
+
+# ----------------------------------------------------------------------------- decisions on a threshold (hand-built cases)
+def test_corner_eigenvalue_ratio_gate(pkg, oracle, hip):
+    """cornerOptimization accepts a line only if the largest eigenvalue of the 5-neighbour covariance exceeds 3x the second
+    (mapOptimization.cpp:1052).  Clusters built so that the ratio is KNOWN (five points on a cross: variance a^2 2/5 along x,
+    b^2 2/5 along y → ratio (a/b)^2) sweep the gate from 2 to 4.5; away from the threshold the decision is the analytic one in
+    both libraries, and the two libraries agree everywhere (Jacobi in f32 on both sides; cv::eigen itself is not available:
+    parity unpinned)"""
+    P = dict(N_SCAN=4, Horizon_SCAN=2048, max_raw_points=8192, max_map_points=65536, mappingCornerLeafSize=0.05)
+    o = pkg.LidarHotpath(oracle, **P); g = pkg.LidarHotpath(hip, **P)
+    ratios = np.concatenate([np.linspace(2.0, 2.9, 10), [2.97, 2.99, 2.999, 3.001, 3.01, 3.03], np.linspace(3.1, 4.5, 10)])
+    b = 0.12
+    clusters, queries, expect = [], [], []
+    for i, r in enumerate(ratios):
+        a = b * np.sqrt(r)
+        c = np.array([6.0 * (i % 6) - 15.0, 6.0 * (i // 6) - 12.0, 1.0])
+        clusters += [c, c + [a, 0, 0], c - [a, 0, 0], c + [0, b, 0], c - [0, b, 0]]
+        queries.append(c + [0.02, 0.03, 0.05])
+        expect.append(r > 3.0)
+    m = np.zeros((len(clusters), 4), np.float32); m[:, :3] = np.array(clusters)
+    q = np.zeros((len(queries), 4), np.float32); q[:, :3] = np.array(queries)
+    pad = np.zeros((200, 4), np.float32); pad[:, :3] = np.random.default_rng(0).uniform(200, 300, (200, 3))      # far-away filler
+    flags = []
+    for h in (o, g):
+        h.map_set(np.concatenate([m, pad]), np.concatenate([m, pad]))
+        assert h.counts()["map_corner_ds"] == len(m) + len(pad)          # 5 cm leaf: nothing merged
+        r = h.scan_to_map(q, np.concatenate([q, pad[:150]]), np.zeros(6, np.float32))      # corner queries = the cluster centres, identity pose
+        _, fl = h.debug_residuals(0, np.zeros(6, np.float32))
+        flags.append(fl[:len(q)].astype(bool))
+    np.testing.assert_array_equal(flags[0], flags[1])
+    clear = np.abs(ratios - 3.0) > 0.02
+    np.testing.assert_array_equal(flags[1][clear], np.array(expect)[clear])
+    o.close(); g.close()
