@@ -276,9 +276,15 @@ def main():
     tracker_out = None
     if not args.no_tracker:
         try:
-            tracker_out = bench_tracker(pkg, hip, local_rank, rank, world, dist if world > 1 else None, dev, args.tracker_seconds)
+            tracker_out = bench_tracker(pkg, hip, local_rank, rank, world, args.tracker_seconds)
         except Exception as e:                      # noqa: BLE001 — the tracker leg must not hide the headline
-            tracker_out = dict(error=str(e))
+            tracker_out = dict(error=str(e), value=0.0)
+        if world > 1:                               # outside the try: every rank issues this collective, whatever its leg did
+            tr = torch.tensor([float(tracker_out.get("value", 0.0))], dtype=torch.float64, device=dev)
+            allr = [torch.zeros_like(tr) for _ in range(world)]
+            dist.all_gather(allr, tr)
+            tracker_out["per_rank"] = [round(float(x[0]), 1) for x in allr]
+            tracker_out["value"] = round(float(sum(tracker_out["per_rank"])), 1)
 
     # ---------------------------------------------------------------- sequential mode (secondary figure, rank 0)
     seq_out = None
@@ -522,7 +528,7 @@ def bench_sequential(pkg, hip, device, dev, n_scans, n_raw, n_keyframes, kf_n_ra
     return out
 
 
-def bench_tracker(pkg, hip, device, rank, world, dist, dev, seconds):
+def bench_tracker(pkg, hip, device, rank, world, seconds):
     """LK frames/sec at 1280x720, 150 features, 4 pyramid levels (config 4 of BASELINE.json).  Frame pair i belongs to rank
     i mod world; every rank tracks its share for >= `seconds`, the per-rank rates are gathered and summed."""
     import torch
@@ -593,14 +599,8 @@ def bench_tracker(pkg, hip, device, rank, world, dist, dev, seconds):
         node.close()
     except Exception as e:                      # noqa: BLE001
         node_fps = dict(error=str(e))
-    total_rate = rate
+    total_rate = rate                               # this rank's share; main() gathers and sums the ranks
     per_rank = [rate]
-    if world > 1:
-        tr = torch.tensor([rate], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(tr) for _ in range(world)]
-        dist.all_gather(allr, tr)
-        per_rank = [float(x[0]) for x in allr]
-        total_rate = float(sum(per_rank))
     t.close()
 
     def rl(nbytes, us, note):
