@@ -338,11 +338,18 @@ __global__ __launch_bounds__(256) void vox_heads_assign_kernel(Batch<VoxArgs> B_
 }
 
 // Fixed-point image of one coordinate relative to its voxel's own origin / the exact mean back in f32 (VoxGrid, lvi_voxel.hpp)
+// round-to-nearest-even of |x| < 2^51 to an integer: one f64 add (the sum's ulp is 1) instead of the ~20 instructions of the
+// general f64 -> i64 conversion, which gfx950 does not have; the same value for every such x
+__device__ __forceinline__ long long d2ll_rn_small(double x)
+{
+    const double M = 6755399441055744.0;                            // 2^52 + 2^51
+    return __double_as_longlong(x + M) - __double_as_longlong(M);
+}
 __device__ __forceinline__ unsigned long long fx_xyz(float v, int cell, double leaf, int k)
 {
-    return (unsigned long long)__double2ll_rn(ldexp((double)v - (double)cell * leaf, k));       // two's complement: sums wrap correctly
+    return (unsigned long long)d2ll_rn_small(ldexp((double)v - (double)cell * leaf, k));        // |.| < 2^38 (vox_fx_setup); two's complement: sums wrap correctly
 }
-__device__ __forceinline__ unsigned long long fx_int(float v, int k) { return (unsigned long long)__double2ll_rn(ldexp((double)v, k)); }
+__device__ __forceinline__ unsigned long long fx_int(float v, int k) { return (unsigned long long)d2ll_rn_small(ldexp((double)v, k)); }
 __device__ __forceinline__ float fx_mean_xyz(unsigned long long sum, unsigned cnt, int cell, double leaf, int k)
 {
     return (float)((double)cell * leaf + ldexp(__ll2double_rn((long long)sum) / (double)cnt, -k));
@@ -658,20 +665,22 @@ struct VbCells {
     unsigned cn[1 << VB_CL_LOG];
 };
 
+template <int NT = 256>
 __device__ __forceinline__ void vb_zero(VbCells& L, int cells)
 {
-    for (int c = threadIdx.x; c < cells; c += 256) { L.sx[c] = 0ull; L.sy[c] = 0ull; L.sz[c] = 0ull; L.si[c] = 0ull; L.cn[c] = 0u; }
+    for (int c = threadIdx.x; c < cells; c += NT) { L.sx[c] = 0ull; L.sy[c] = 0ull; L.sz[c] = 0ull; L.si[c] = 0ull; L.cn[c] = 0u; }
     __syncthreads();
 }
 
 // add bucketed points [q0, q1) whose voxel idx lies in [k0, k0 + cells) to the LDS accumulators
+template <int NT = 256>
 __device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, const lvi_pt* __restrict__ pts, int q0, int q1, unsigned k0, int cells)
 {
     constexpr int NL = 8;                               // loads in flight per lane
-    for (int i0 = q0 + threadIdx.x; i0 < q1; i0 += NL * 256) {
+    for (int i0 = q0 + threadIdx.x; i0 < q1; i0 += NL * NT) {
         lvi_pt p[NL]; bool ok[NL];
 #pragma unroll
-        for (int u = 0; u < NL; u++) { ok[u] = i0 + u * 256 < q1; if (ok[u]) p[u] = pts[i0 + u * 256]; }
+        for (int u = 0; u < NL; u++) { ok[u] = i0 + u * NT < q1; if (ok[u]) p[u] = pts[i0 + u * NT]; }
 #pragma unroll
         for (int u = 0; u < NL; u++) {
             if (!ok[u]) continue;
@@ -689,19 +698,27 @@ __device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, cons
 
 // ordered compaction of the occupied voxels of the sweep into the staging area (thread t owns voxels 4t..4t+3);
 // returns the number written
-__device__ __forceinline__ int vb_emit(const VbCells& L, const VoxGrid& g, lvi_pt* __restrict__ stg, uint2* __restrict__ skc, int at, unsigned k0, int cells, int* ws)
+template <int NT = 256>
+__device__ __forceinline__ int vb_emit(const VbCells& L, const VoxGrid& g, lvi_pt* __restrict__ stg, uint2* __restrict__ skc, int at, unsigned k0, int cells, int* ws,
+                                       unsigned short* cl)
 {
+    // the occupied cells, in idx order, first as a list in LDS (thread t scans cells PER t .. PER t + PER - 1), then one
+    // centroid per thread: a bin of a dense map has ~90 occupied cells, which 90 threads finish in one step instead of
+    // ~25 threads in four
+    constexpr int PER = (1 << VB_CL_LOG) / NT;
     const int tid = threadIdx.x;
     int c4 = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const int c = tid * 4 + j; c4 += c < cells && L.cn[c] != 0u; }
+    for (int j = 0; j < PER; j++) { const int c = tid * PER + j; c4 += c < cells && L.cn[c] != 0u; }
     int tot;
-    int r = at + block_excl_scan<256>(c4, ws, &tot);
+    int r = block_excl_scan<NT>(c4, ws, &tot);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int c = tid * 4 + j;
-        const unsigned m = c < cells ? L.cn[c] : 0u;
-        if (m) { stg[r] = fx_centroid(g, k0 + (unsigned)c, L.sx[c], L.sy[c], L.sz[c], L.si[c], m); skc[r] = make_uint2(k0 + (unsigned)c, m); r++; }
+    for (int j = 0; j < PER; j++) { const int c = tid * PER + j; if (c < cells && L.cn[c] != 0u) cl[r++] = (unsigned short)c; }
+    __syncthreads();
+    for (int q = tid; q < tot; q += NT) {
+        const int c = cl[q];
+        const unsigned m = L.cn[c];
+        stg[at + q] = fx_centroid(g, k0 + (unsigned)c, L.sx[c], L.sy[c], L.sz[c], L.si[c], m); skc[at + q] = make_uint2(k0 + (unsigned)c, m);
     }
     __syncthreads();
     return tot;
@@ -710,7 +727,8 @@ __device__ __forceinline__ int vb_emit(const VbCells& L, const VoxGrid& g, lvi_p
 // One workgroup per chunk of <= VB_CH bucketed points of one bin.  A bin that is a single chunk is finished here;
 // the chunks of a larger bin leave their LDS tables in chunkTab and vb_merge adds them up (no global atomics,
 // so a bin with 10^5 points is spread over 25 workgroups instead of keeping one busy for 0.2 ms).
-__global__ __launch_bounds__(256) void vb_accum_kernel(Batch<VoxArgs> B_)
+template <int NT>
+__global__ __launch_bounds__(NT) void vb_accum_kernel(Batch<VoxArgs> B_)
 {
     const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
@@ -718,15 +736,17 @@ __global__ __launch_bounds__(256) void vb_accum_kernel(Batch<VoxArgs> B_)
     const int nbins = g.nbins, sh = g.bin_shift;
     if (nbins == 0) return;
     __shared__ VbCells L;
-    __shared__ unsigned occ[1024];                                          // occupied sub-ranges of a wide bin
+    __shared__ unsigned occ[32];                                            // occupied sub-ranges of a wide bin, one bit each
+    __shared__ unsigned short cl[1 << VB_CL_LOG];                           // vb_emit's list of occupied cells
     static_assert(VB_NB == 4096 && VB_CL_LOG == 10, "occ[] is sized for 2^32 / VB_NB / 2^VB_CL_LOG sub-ranges");
-    __shared__ int ws[8];
+    __shared__ int ws[NT / 64 + 1];
     const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
     const int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
     const int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
     const lvi_pt* __restrict__ pts = a.bucketed + (size_t)s * a.seg_cap;
     lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
     uint2* __restrict__ skc = a.stagingKC + (size_t)s * a.seg_cap;
+    constexpr int PER = (1 << VB_CL_LOG) / NT;
     const int tid = threadIdx.x;
     const int nchunks = cs[nbins];
     const int cells = sh >= VB_CL_LOG ? (1 << VB_CL_LOG) : (1 << sh);
@@ -738,36 +758,47 @@ __global__ __launch_bounds__(256) void vb_accum_kernel(Batch<VoxArgs> B_)
         if (sh > VB_CL_LOG) {
             // wide bin (sparse grid): one workgroup, one sweep per occupied 1024-voxel sub-range
             const int nsub = 1 << (sh - VB_CL_LOG);
-            for (int q = tid; q < nsub; q += 256) occ[q] = 0u;
+            if (tid < 32) occ[tid] = 0u;
             __syncthreads();
-            for (int i = p0 + tid; i < p1; i += 256) occ[(vox_key_of_pt(g, pts[i]) - kbase) >> VB_CL_LOG] = 1u;
+            for (int i = p0 + tid; i < p1; i += NT) { const unsigned q = (vox_key_of_pt(g, pts[i]) - kbase) >> VB_CL_LOG; atomicOr(&occ[q >> 5], 1u << (q & 31)); }
             __syncthreads();
             int carry = 0;
             for (int sp = 0; sp < nsub; sp++) {
-                if (!occ[sp]) continue;                                     // same for every thread
+                if (!((occ[sp >> 5] >> (sp & 31)) & 1u)) continue;             // same for every thread
                 const unsigned k0 = kbase + ((unsigned)sp << VB_CL_LOG);
-                vb_zero(L, cells);
-                vb_add_points(L, g, pts, p0, p1, k0, cells);
-                carry += vb_emit(L, g, stg, skc, p0 + carry, k0, cells, ws);
+                vb_zero<NT>(L, cells);
+                vb_add_points<NT>(L, g, pts, p0, p1, k0, cells);
+                carry += vb_emit<NT>(L, g, stg, skc, p0 + carry, k0, cells, ws, cl);
             }
             if (tid == 0) a.binVox[(size_t)s * VB_NB + b] = carry;
             continue;
         }
         const int q0 = p0 + j * VB_CH, q1 = min(p1, q0 + VB_CH);
-        vb_zero(L, cells);
-        vb_add_points(L, g, pts, q0, q1, kbase, cells);
+        vb_zero<NT>(L, cells);
+        vb_add_points<NT>(L, g, pts, q0, q1, kbase, cells);
         if (nch == 1) {
-            const int tot = vb_emit(L, g, stg, skc, p0, kbase, cells, ws);
+            const int tot = vb_emit<NT>(L, g, stg, skc, p0, kbase, cells, ws, cl);
             if (tid == 0) a.binVox[(size_t)s * VB_NB + b] = tot;
         } else {
-            // leave the table in global memory for vb_merge.  (Letting the workgroup that finishes a bin's last chunk add
-            // them up needs a device-scope fence per chunk; on a multi-XCD part every such fence writes back and invalidates
-            // the XCD's L2 — measured 257 us instead of 41 + 19 us for the 4.9M-point map.)
-            unsigned long long* tv = a.chunkTabV + ((size_t)s * a.max_multi + ms[b] + j) * (size_t)(4 << VB_CL_LOG);
-            unsigned* tc = a.chunkTabC + ((size_t)s * a.max_multi + ms[b] + j) * (size_t)(1 << VB_CL_LOG);
-            for (int c = tid; c < cells; c += 256) {
-                tv[c] = L.sx[c]; tv[cells + c] = L.sy[c]; tv[2 * cells + c] = L.sz[c]; tv[3 * cells + c] = L.si[c]; tc[c] = L.cn[c];
+            // leave the OCCUPIED cells of the table in global memory for vb_merge, compacted (a bin of a dense map holds ~90
+            // voxels in its 1024 cells: 4 KB instead of the 36 KB of the whole table, written and read once per chunk).
+            // (Letting the workgroup that finishes a bin's last chunk add them up needs a device-scope fence per chunk; on a
+            // multi-XCD part every such fence writes back and invalidates the XCD's L2 — measured 257 us instead of 41 + 19 us
+            // for the 4.9M-point map.)
+            unsigned long long* tv = a.chunkTabV + ((size_t)s * a.max_multi + ms[b] + j) * (size_t)(4 * VB_TAB);
+            unsigned* tc = a.chunkTabC + ((size_t)s * a.max_multi + ms[b] + j) * (size_t)VB_TABC;
+            int c4 = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const int c = tid * PER + q; c4 += c < cells && L.cn[c] != 0u; }
+            int tot;
+            int r = block_excl_scan<NT>(c4, ws, &tot);
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int c = tid * PER + q;
+                const unsigned m = c < cells ? L.cn[c] : 0u;                 // m <= VB_CH < 2^16, c < 2^10
+                if (m) { tv[r] = L.sx[c]; tv[VB_TAB + r] = L.sy[c]; tv[2 * VB_TAB + r] = L.sz[c]; tv[3 * VB_TAB + r] = L.si[c]; tc[r] = ((unsigned)c << 16) | m; r++; }
             }
+            if (tid == 0) tc[VB_TAB] = (unsigned)tot;
             __syncthreads();
         }
     }
@@ -783,6 +814,7 @@ __global__ __launch_bounds__(256) void vb_merge_kernel(Batch<VoxArgs> B_)
     if (nbins == 0 || sh > VB_CL_LOG) return;
     __shared__ VbCells L;
     __shared__ int ws[8];
+    __shared__ unsigned short cl[1 << VB_CL_LOG];
     const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
     const int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
     const int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
@@ -793,18 +825,35 @@ __global__ __launch_bounds__(256) void vb_merge_kernel(Batch<VoxArgs> B_)
         const int nch = cs[b + 1] - cs[b];
         if (nch <= 1) continue;
         const size_t t0 = (size_t)s * a.max_multi + ms[b];
-        for (int c = threadIdx.x; c < cells; c += 256) {
-            unsigned long long x = 0, y = 0, z = 0, w = 0; unsigned m = 0;
-#pragma unroll 4
-            for (int j = 0; j < nch; j++) {
-                const unsigned long long* tv = a.chunkTabV + (t0 + j) * (size_t)(4 << VB_CL_LOG);
-                const unsigned* tc = a.chunkTabC + (t0 + j) * (size_t)(1 << VB_CL_LOG);
-                x += tv[c]; y += tv[cells + c]; z += tv[2 * cells + c]; w += tv[3 * cells + c]; m += tc[c];
+        vb_zero(L, cells);
+        // wavefront w adds chunks w, w + 4, ...: entries of one chunk name distinct cells, chunks meet through LDS atomics;
+        // four entries per lane in flight, the next chunk's entry count fetched with them
+        const int wv = threadIdx.x >> 6, ln = lane_id();
+        int ne = wv < nch ? (int)(a.chunkTabC + (t0 + wv) * (size_t)VB_TABC)[VB_TAB] : 0;
+        for (int j = wv; j < nch; j += 4) {
+            const unsigned long long* tv = a.chunkTabV + (t0 + j) * (size_t)(4 * VB_TAB);
+            const unsigned* tc = a.chunkTabC + (t0 + j) * (size_t)VB_TABC;
+            const int ne_next = j + 4 < nch ? (int)(tc + 4 * (size_t)VB_TABC)[VB_TAB] : 0;
+            for (int r0 = ln; r0 < ne; r0 += 256) {
+                unsigned e[4]; unsigned long long x[4], y[4], z[4], w[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int r = r0 + 64 * u;
+                    e[u] = 0u;
+                    if (r < ne) { e[u] = tc[r]; x[u] = tv[r]; y[u] = tv[VB_TAB + r]; z[u] = tv[2 * VB_TAB + r]; w[u] = tv[3 * VB_TAB + r]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (!e[u]) continue;                                     // a real entry has a count >= 1
+                    const int c = (int)(e[u] >> 16);
+                    atomicAdd(&L.sx[c], x[u]); atomicAdd(&L.sy[c], y[u]); atomicAdd(&L.sz[c], z[u]); atomicAdd(&L.si[c], w[u]);
+                    atomicAdd(&L.cn[c], e[u] & 0xFFFFu);
+                }
             }
-            L.sx[c] = x; L.sy[c] = y; L.sz[c] = z; L.si[c] = w; L.cn[c] = m;
+            ne = ne_next;
         }
         __syncthreads();
-        const int tot = vb_emit(L, g, stg, skc, bs[b], (unsigned)b << sh, cells, ws);
+        const int tot = vb_emit(L, g, stg, skc, bs[b], (unsigned)b << sh, cells, ws, cl);
         if (threadIdx.x == 0) a.binVox[(size_t)s * VB_NB + b] = tot;
     }
 }
@@ -1260,7 +1309,8 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
         // grid-stride over the chunks: at most ceil(n / VB_CH) + bins of them exist; a small plan (ring / scan grids: 64 bins) gets
         // a small grid — every workgroup of this kernel owns 40 KB of LDS, and thousands of idle ones cost 40 us of dispatch
         const dim3 ga(std::max(64, std::min(2 * div_up(p.seg_cap, VB_CH) + 64, 2048)), p.nseg, S);
-        LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel, ga, dim3(256), 0, ctx.stream, B));
+        // 256 threads: 128 / 512 / 1024 measured 172 / 163 / 231 us instead of 136 for four slots of the 4.87 M-point map
+        LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel<256>, ga, dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, gb, dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[11], 0, hipLaunchKernelGGL(vb_outscan_kernel, dim3(1, 1, S), dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[12], 0, hipLaunchKernelGGL(vb_copy_kernel, gb, dim3(256), 0, ctx.stream, B));

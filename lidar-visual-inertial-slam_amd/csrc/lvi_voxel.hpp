@@ -45,6 +45,8 @@ constexpr int VB_STILE = 4096;   // binned path: points per workgroup of the sca
 constexpr int VB_PAD = 1;        // binned path: stride of the global bin counters / cursors (one per 64-B line, VB_PAD = 16, measured SLOWER: hist 36 vs 29 us, scatter 67 vs 56 us)
 constexpr int VB_WG = 512;       // deterministic partition: workgroups (= contiguous point ranges) per segment (256 / 512 / 1024: scatter 62 / 44 / 46 us on the 4.87 M-point map)
 constexpr int VB_CH = 4096;      // binned path: points per accumulate workgroup (chunk of a bin)
+constexpr int VB_TAB = 1 << VB_CL_LOG;      // entries per compacted chunk table
+constexpr int VB_TABC = VB_TAB + 32;         // u32 words per chunk table: entries, then the entry count
 constexpr int VB_ACC_BLOCKS = 1024;
 enum VoxMode { VOX_AUTO = 0, VOX_SORTED = 1, VOX_BINNED = 2 };
 
@@ -79,8 +81,8 @@ struct VoxelPlan {
     int* d_multiStart = nullptr;      // [nseg][VB_NB+1]  … of the chunks of bins with more than one chunk
     int* d_chunkBin = nullptr;        // [nseg][max_chunks] bin of every chunk (saves the accumulate kernel a 12-step search through L2)
     int max_chunks = 0;
-    unsigned long long* d_chunkTabV = nullptr;   // [nseg][max_multi][4][1024] chunk tables of multi-chunk bins
-    unsigned* d_chunkTabC = nullptr;             // [nseg][max_multi][1024]
+    unsigned long long* d_chunkTabV = nullptr;   // [nseg][max_multi][4][VB_TAB] compacted chunk tables of multi-chunk bins (sums of the occupied cells)
+    unsigned* d_chunkTabC = nullptr;             // [nseg][max_multi][VB_TABC]: (cell << 16 | count) per entry, entry count at [VB_TAB]
     int max_multi = 0;
     unsigned long long* h_ncells = nullptr;   // pinned host, [nseg]: div_b product of the latest run (AUTO's hint)
     mutable int last_mode = VOX_SORTED;       // what the latest voxel_downsample_batch enqueued
@@ -118,8 +120,8 @@ struct VoxelPlan {
         max_chunks = div_up(seg_cap_, VB_CH) + VB_NB;
         d_chunkBin = ar.template alloc<int>((size_t)nseg_ * max_chunks);
         max_multi = 2 * div_up(seg_cap_, VB_CH) + 2;         // sum of ceil(cnt/CH) over bins with cnt > CH  <=  2 n / CH
-        d_chunkTabV = ar.template alloc<unsigned long long>((size_t)nseg_ * max_multi * (4 << VB_CL_LOG));
-        d_chunkTabC = ar.template alloc<unsigned>((size_t)nseg_ * max_multi * (1 << VB_CL_LOG));
+        d_chunkTabV = ar.template alloc<unsigned long long>((size_t)nseg_ * max_multi * (4 * VB_TAB));
+        d_chunkTabC = ar.template alloc<unsigned>((size_t)nseg_ * max_multi * VB_TABC);
     }
     void release();                                                            // frees h_ncells
     void set_static(const Ctx& ctx, const VoxSegStatic* host_segs);           // H2D of the per-segment pointers (+ the pinned hint)
