@@ -55,7 +55,7 @@ def parse():
                     help="steps kept enqueued per handle in the rolling form (0 = sync every handle after every step)")
     ap.add_argument("--inflight", type=int, default=4,
                     help="independent handles per GPU (own streams, own DS map / index replicas); with --batch S each carries S scans per step")
-    ap.add_argument("--batch", type=int, default=4,
+    ap.add_argument("--batch", type=int, default=8,
                     help="scans per launch sequence (lvi_scan_batch_*): every kernel of the path carries the scan index in blockIdx.z. "
                          "1 = the single-scan entry points")
     ap.add_argument("--enqueue", choices=["graph", "eager"], default="eager",

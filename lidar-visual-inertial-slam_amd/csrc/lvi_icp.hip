@@ -209,7 +209,8 @@ __device__ __forceinline__ void knn_insert(KnnKeys& r, unsigned long long key)
 constexpr float KNN_R2_FULL = 0x1.fffffep-1f;
 template <int G, int KNN_KB>
 __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
-                                                  float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr, float r2max = KNN_R2_FULL)
+                                                  float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr, float r2max = KNN_R2_FULL,
+                                                  float* lb2 = nullptr)
 {
     constexpr int KNN_RPL = (25 + G - 1) / G;         // rows per lane
 #define LVI_KT(slot) do { if (tk) tk[slot] = clock64(); } while (0)
@@ -217,6 +218,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
     KnnKeys r;
 #pragma unroll
     for (int k = 0; k < 5; k++) r.k[k] = KNN_EMPTY;
+    unsigned rej = 0x7F800000u;                       // smallest squared distance (float bits) among the candidates that lose their place
     if (m.ok && m.n > 0) {
         const float e = (float)m.edge, inv_e = (float)m.inv_edge;
         // cell of the query (double, as cell_of) and its position inside that cell in [0,1) (f32 is plenty: the row
@@ -285,7 +287,9 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 // Only neighbours closer than 1 m can matter: the callers reject a feature unless its 5th neighbour has
                 // sqDis < 1.0, and if five such neighbours exist they ARE the five nearest.
                 const bool take = f0 + u < T && dist <= r2max;
-                knn_insert(r, take ? knn_key(dist, __float_as_int(p[u].intensity)) : KNN_EMPTY);
+                const unsigned long long key = take ? knn_key(dist, __float_as_int(p[u].intensity)) : KNN_EMPTY;
+                if (lb2) { const unsigned dr = (unsigned)((key < r.k[4] ? r.k[4] : key) >> 32); rej = dr < rej ? dr : rej; }
+                knn_insert(r, key);
             }
         }
     }
@@ -299,6 +303,15 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         for (int o = G / 2; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(h, o, 64); h = v < h ? v : h; }
         out.d[k] = __uint_as_float((unsigned)(h >> 32)); out.i[k] = (int)(unsigned)h;
         if (r.k[0] == h && h != KNN_EMPTY) { r.k[0] = r.k[1]; r.k[1] = r.k[2]; r.k[2] = r.k[3]; r.k[3] = r.k[4]; r.k[4] = KNN_EMPTY; }
+    }
+    if (lb2) {
+        // every map point outside the five is either a candidate that lost its place (in a lane's list or in the merge: the
+        // smallest such distance is rej / a lane's remaining head), or was never taken: farther than sqrt(r2max)
+        const unsigned hd = (unsigned)(r.k[0] >> 32);
+        rej = hd < rej ? hd : rej;
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) { const unsigned v = __shfl_xor(rej, o, 64); rej = v < rej ? v : rej; }
+        *lb2 = fminf(__uint_as_float(rej), r2max);
     }
 }
 
@@ -458,6 +471,9 @@ struct IcpArgs {
     const float* pose_init;                       // [6] initial guess (device)
     int have_map;
     int* nn_prev;                                 // [Q][5] neighbours of the previous iteration (-1: fewer than five within 1 m)
+    float4* nn_ref;                               // [Q] where the feature stood at its last search (xyz) and a lower bound (w, squared) on the distance from there
+                                                  // to every map point outside its five; nullptr: search in every iteration
+    float knn_slack;                              // metres added to the radius of a bounded search (room for later iterations to skip theirs)
 };
 
 __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
@@ -567,48 +583,101 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
     __shared__ float sA[12], sT[6];
     __shared__ double srow[ICP_QPB][28];
     __shared__ Knn5 snn[ICP_QPB];
+    __shared__ float sr2[ICP_QPB];                  // search radius (squared) of the features that search, in list order
+    __shared__ unsigned char slist[ICP_QPB];        // the features (workgroup-local) that search in this iteration
+    __shared__ int snsearch;
     if (threadIdx.x < 12) sA[threadIdx.x] = a.st->pose.A[threadIdx.x];
     if (threadIdx.x < 6) sT[threadIdx.x] = a.st->pose.trig[threadIdx.x];
     __syncthreads();
-    {
-        const int ql = threadIdx.x / G, sub = threadIdx.x % G;
+    // Phase 0, first wavefront, one lane per feature.  From the second iteration on a feature knows its previous five
+    // neighbours; their distances under the new pose bound the fifth-nearest distance (five map points lie inside that ball),
+    // and the search either shrinks to that ball or is not needed at all: the feature's last search left a lower bound LB on
+    // the distance from where it stood THEN (ref) to every map point outside its five, so every such point is at least
+    // LB - |sel - ref| away now; if that exceeds the farthest of the five (with 2e-4 m of room for the f32 rounding of the
+    // distances, 1e-6 relative), the five are still the five nearest, no outsider can even tie, and their (distance, index)
+    // order is recomputed here with the search's own expression: the same Knn5, bit for bit, without a search.
+    if (threadIdx.x < ICP_QPB) {
+        const int ql = threadIdx.x;
         const int t = blockIdx.x * ICP_QPB + ql;
         const bool active = t < nC + nS;
-        const bool isC = t < nC;
-        lvi_pt ori = {0.f, 0.f, 0.f, 0.f};
-        if (active) ori = isC ? a.q[0][t] : a.q[1][t - nC];
-        const lvi_pt sel = to_map(sA, ori);
-        const int w = (active && !isC) ? 1 : 0;
-        LVI_STAMP(0);
-        Knn5 r;
-        long long tk[6] = {0, 0, 0, 0, 0, 0};
-        // from the second iteration on: bound the search by the previous neighbours' distances under the new pose
+        bool need = active;
         float r2 = KNN_R2_FULL;
         if (active && a.nn_prev && a.st->iters > 0) {
+            const bool isC = t < nC;
+            const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
+            const lvi_pt sel = to_map(sA, ori);
             const int* __restrict__ pn = a.nn_prev + (size_t)t * 5;
-            const int i0 = pn[0];
-            if (i0 >= 0) {
-                const lvi_pt* __restrict__ map = a.mapds[w];
+            int id[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) id[j] = pn[j];
+            if (id[0] >= 0) {
+                const lvi_pt* __restrict__ map = a.mapds[isC ? 0 : 1];
+                KnnKeys kk;
+#pragma unroll
+                for (int j = 0; j < 5; j++) kk.k[j] = KNN_EMPTY;
                 float b = 0.f;
 #pragma unroll
                 for (int j = 0; j < 5; j++) {
-                    const lvi_pt p = map[j == 0 ? i0 : pn[j]];
+                    const lvi_pt p = map[id[j]];
                     const float ex = sub_rn(sel.x, p.x), ey = sub_rn(sel.y, p.y), ez = sub_rn(sel.z, p.z);
-                    b = fmaxf(b, add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez)));
+                    const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+                    b = fmaxf(b, dist);
+                    knn_insert(kk, knn_key(dist, id[j]));
                 }
-                if (b < 1.0f) r2 = b;
+                if (b < 1.0f) {
+                    const float rb = sqrtf(b);
+                    if (a.nn_ref) {
+                        const float4 ref = a.nn_ref[t];
+                        const float dx = sel.x - ref.x, dy = sel.y - ref.y, dz = sel.z - ref.z;
+                        if (rb + sqrtf(dx * dx + dy * dy + dz * dz) + 2e-4f < sqrtf(ref.w)) {
+                            Knn5 r;
+#pragma unroll
+                            for (int j = 0; j < 5; j++) { r.d[j] = __uint_as_float((unsigned)(kk.k[j] >> 32)); r.i[j] = (int)(unsigned)kk.k[j]; }
+                            snn[ql] = r;
+                            need = false;
+                        }
+                    }
+                    const float rs = rb + a.knn_slack;
+                    r2 = fminf(fmaxf(b, rs * rs), KNN_R2_FULL);
+                }
             }
         }
-        if (active) knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2);
-        if (active && sub == 0) snn[ql] = r;
-        if (active && sub == 0 && a.nn_prev) {
-            int* __restrict__ pn = a.nn_prev + (size_t)t * 5;
-            const bool five = r.d[4] < 1.0f;
+        const unsigned long long mk = __ballot(need);
+        if (need) { const int pos = __popcll(mk & ((1ull << ql) - 1ull)); slist[pos] = (unsigned char)ql; sr2[pos] = r2; }
+        if (ql == 0) snsearch = __popcll(mk);
+    }
+    LVI_STAMP(0);
+    __syncthreads();
+    // Phase A: G lanes per SEARCHING feature, packed to the front of the workgroup (wavefronts beyond the list have nothing to do)
+    {
+        const int gi = threadIdx.x / G, sub = threadIdx.x % G;
+        long long tk[6] = {0, 0, 0, 0, 0, 0};
+        float r2 = KNN_R2_FULL;
+        if (gi < snsearch) {
+            const int ql = slist[gi];
+            const int t = blockIdx.x * ICP_QPB + ql;
+            const bool isC = t < nC;
+            const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
+            const lvi_pt sel = to_map(sA, ori);
+            const int w = isC ? 0 : 1;
+            r2 = sr2[gi];
+            Knn5 r;
+            float lb2 = 0.f;
+            knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref ? &lb2 : nullptr);
+            if (sub == 0) {
+                snn[ql] = r;
+                if (a.nn_prev) {
+                    int* __restrict__ pn = a.nn_prev + (size_t)t * 5;
+                    const bool five = r.d[4] < 1.0f;
 #pragma unroll
-            for (int j = 0; j < 5; j++) pn[j] = five ? r.i[j] : -1;
+                    for (int j = 0; j < 5; j++) pn[j] = five ? r.i[j] : -1;
+                    if (a.nn_ref) a.nn_ref[t] = make_float4(sel.x, sel.y, sel.z, five ? lb2 : 0.f);
+                }
+            }
         }
         LVI_STAMP(1);
         if (stamp) { cyc[6] = tk[1] - tk[0]; cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; a.cyc[13] = tk[5]; a.cyc[14] = r2 < KNN_R2_FULL ? 1 : 0; }
+        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&a.cyc[15], (unsigned long long)snsearch);      // searches of this scan match, all iterations
     }
     __syncthreads();
     if (threadIdx.x < ICP_QPB) {
@@ -691,6 +760,7 @@ __global__ void icp_init_kernel(Batch<IcpArgs> B_)
     for (int k = 0; k < 6; k++) s.pose.T[k] = pose_init[k];
     make_pose(s.pose);
     s.done = 0; s.converged = 0; s.iters = 0; s.any_lm = 0; s.status = LVI_OK;
+    a.cyc[15] = 0;                                 // searches counted by the residual kernel (debug read-out)
     for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) s.n_sel[i] = 0;
     if (!have_map) { s.done = 1; s.status = LVI_NO_MAP; return; }                              // :1317
     if (!(a.nq[0] > a.edgeMin && a.nq[1] > a.surfMin)) { s.done = 1; s.status = LVI_TOO_FEW_FEATURES; }   // :1320
@@ -1009,6 +1079,7 @@ IcpArgs icp_args(LidarDev& d)
     for (int w = 0; w < 2; w++) { a.meta[w] = d.grid[w].meta; a.cell_start[w] = d.grid[w].cell_start; a.sorted[w] = d.grid[w].sorted; }
     a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
     a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles; a.d_status = d.d_status; a.nn_prev = d.knn_bound ? d.nnPrev : nullptr;
+    a.nn_ref = (d.knn_bound && d.knn_skip) ? d.nnRef : nullptr; a.knn_slack = d.knn_slack;
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;

@@ -107,6 +107,9 @@ struct LidarDev {
     int* nnPrev = nullptr;                                 // [ext_cap][5] neighbours found by the previous GN iteration
     int icp_g0 = 4;                                        // lanes per feature in GN iteration 0 (whole unit ball; LVI_ICP_G0; measured with 16 scans in flight: 8 lanes 5 030, 4 lanes 5 245 scans/s)
     int icp_g1 = 4;                                        // lanes per feature in GN iterations >= 1 (LVI_ICP_G1 = 8 | 4 | 2 | 84 (8 lanes, batches of 4))
+    float4* nnRef = nullptr;                               // [ext_cap] position at the feature's last search + squared lower bound on the distance to the map points outside its five
+    bool knn_skip = true;                                  // LVI_KNN_NO_SKIP=1 at create: every iteration >= 1 runs its (bounded) search (tests: same bits)
+    float knn_slack = 0.05f;                               // LVI_KNN_SLACK (m): radius added to a bounded search so that later iterations can skip theirs
     bool knn_bound = true;                                 // LVI_KNN_NO_BOUND=1 at create: every iteration searches the whole unit ball (tests: same bits)
     int nblk_icp = 0;
     IcpState* h_icp = nullptr;                             // pinned host mirror

@@ -887,6 +887,7 @@ void layout(AR& ar, LidarDev& d)
     d.icpPartial = ar.template alloc<double>((size_t)d.nblk_icp * 28);
     d.coeff = ar.template alloc<lvi_pt>(d.ext_cap); d.flag = ar.template alloc<uint8_t>(d.ext_cap);
     d.nnPrev = ar.template alloc<int>((size_t)d.ext_cap * 5);
+    d.nnRef = ar.template alloc<float4>((size_t)d.ext_cap);
 }
 
 FeatArgs feat_args(LidarDev& d)
@@ -920,6 +921,8 @@ void lidar_allocate(LidarDev& d)
     // and map, 400 MB at 2^24 — so that small handles stay small; a map whose extent needs more gets coarser cells (still exact)
     d.max_cells = (int)std::min<long long>(1ll << 24, std::max<long long>(1ll << 18, 4ll * d.map_cap));
     { const char* e = getenv("LVI_KNN_NO_BOUND"); d.knn_bound = !(e && e[0] == '1'); }
+    { const char* e = getenv("LVI_KNN_NO_SKIP"); d.knn_skip = !(e && e[0] == '1'); }
+    { const char* e = getenv("LVI_KNN_SLACK"); if (e) d.knn_slack = std::max(0.f, (float)atof(e)); }
     { const char* e = getenv("LVI_VB_BINS"); if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && b <= VB_NB) { d.voxMap.bin_pts = a; d.voxMap.bin_max = b; } } }
     if (d.P.batch_scans > 1) d.icp_g1 = 2;        // throughput mode: 16 scans in flight 5 315 scans/s with 2 lanes, 5 140 with 4; one scan alone: 25 vs 20 us per iteration
     { const char* e = getenv("LVI_ICP_G0"); if (e) d.icp_g0 = atoi(e); }

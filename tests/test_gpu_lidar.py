@@ -868,13 +868,19 @@ def test_batched_launches_are_bit_identical(pkg, hip, scene, rebuild):
 
 def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
     """from the second GN iteration on the 5-NN search is bounded by the previous neighbours' distances under the new pose
-    (exact: five map points lie inside that ball).  Same records, selected counts and JtJ bits as searching the unit ball"""
+    (exact: five map points lie inside that ball), and skipped altogether when the lower bound the feature's last search left
+    on the distance to every OTHER map point proves that the five are still the five nearest (several slack radii, incl. 0).
+    Same records, selected counts and JtJ bits as searching the unit ball in every iteration"""
     A = pkg._abi
     S = pkg.synth
     out = []
-    for no_bound in ("0", "1"):
-        monkeypatch.setenv("LVI_KNN_NO_BOUND", no_bound)
-        rows = []
+    modes = (dict(LVI_KNN_NO_BOUND="1"), dict(LVI_KNN_NO_SKIP="1"), dict(), dict(LVI_KNN_SLACK="0"), dict(LVI_KNN_SLACK="0.2"), dict(LVI_ICP_G1="2"))
+    for env in modes:
+        for k in ("LVI_KNN_NO_BOUND", "LVI_KNN_NO_SKIP", "LVI_KNN_SLACK", "LVI_ICP_G1"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rows, searches = [], []
         for kw in (dict(), dict(icp_max_iters=10, icp_disable_break=1)):
             g = pkg.LidarHotpath(hip, **small_params(**kw))
             g.map_set(scene["map_corner"], scene["map_surf"])
@@ -883,17 +889,22 @@ def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
                 g.scan_upload(S.make_scan(20001 - 3000 * k, pose, 60 + k)); g.scan_organize(); g.scan_extract(); g.scan_downsample()
                 r = g.scan_match(S.perturbed_guess(pose, 5 + k))
                 rows.append((bits(r["pose"]), np.array(r["n_sel"]), r["iters"], bits(g.debug_get(A.DBG_ICP_JTJ, np.float32))))
-            cyc = g.debug_get(A.DBG_ICP_CYCLES, np.int64)
-            rows.append((np.array([cyc[14]]),))            # 1: the stamped workgroup of the last launch used a bounded search
+                cyc = g.debug_get(A.DBG_ICP_CYCLES, np.int64)
+                c = g.counts()
+                searches.append((int(cyc[15]), (c["corner_ds"] + c["surf_ds"]) * r["iters"]))
             g.close()
-        out.append(rows)
-    monkeypatch.delenv("LVI_KNN_NO_BOUND")
-    for ra, rb in zip(out[0], out[1]):
-        if len(ra) == 1:
-            assert ra[0][0] == 1 and rb[0][0] == 0
-            continue
-        for x, y in zip(ra, rb):
-            np.testing.assert_array_equal(x, y)
+        out.append((rows, searches))
+    for k in ("LVI_KNN_NO_BOUND", "LVI_KNN_NO_SKIP", "LVI_KNN_SLACK", "LVI_ICP_G1"):
+        monkeypatch.delenv(k, raising=False)
+    for rows, _ in out[1:]:
+        for ra, rb in zip(out[0][0], rows):
+            for x, y in zip(ra, rb):
+                np.testing.assert_array_equal(x, y)
+    # without the skip every feature searches in every iteration; with it most of the later iterations do not
+    for (n, full) in out[0][1] + out[1][1]:
+        assert n == full
+    frac = sum(n for n, _ in out[2][1]) / sum(f for _, f in out[2][1])
+    assert frac < 0.7, frac
 
 
 # ----------------------------------------------------------------------------- decisions on a threshold (hand-built cases)
