@@ -62,6 +62,7 @@ def parse():
                     help="--batch 1 only: one hipGraph launch per scan instead of eager launches")
     ap.add_argument("--map-stream", type=int, default=-1, help="lvi_lidar_params.map_on_main_stream: -1 auto (1 when >= 4 scans in flight), 0, 1")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
+    ap.add_argument("--no-share-map", action="store_true", help="every handle keeps its own copy of the raw map (default: one copy per GPU, lvi_map_share)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-tracker", action="store_true")
     ap.add_argument("--tracker-seconds", type=float, default=0.6)
@@ -145,8 +146,13 @@ def main():
             h.map_assemble(keys)
             h.sync()
     else:
-        for h in hs:
-            h.map_upload_device(d_mc.data_ptr(), nc, d_ms.data_ptr(), ns)
+        # ONE copy of the frozen raw map per GPU: handle 0 holds it, the others read it in place (lvi_map_share) — the
+        # map is a read-only cloud shared by every scan matched against it, and one copy stays in the memory-side cache
+        for b, h in enumerate(hs):
+            if b == 0 or args.no_share_map:
+                h.map_upload_device(d_mc.data_ptr(), nc, d_ms.data_ptr(), ns)
+            else:
+                h.map_share(hs[0])
             h.map_build()
             h.sync()
     cnt_map = g.counts()

@@ -256,6 +256,13 @@ int32_t lvi_scan_match_async(lvi_lidar *h, const float pose_init[6], void *d_rec
  * handle's GPU, e.g. the tensors a replay harness keeps resident); device-to-device, no host sync. */
 int32_t lvi_scan_upload_device(lvi_lidar *h, const void *d_pts, int32_t n_raw);
 int32_t lvi_map_upload_device(lvi_lidar *h, const void *d_corner_raw, int32_t nc, const void *d_surf_raw, int32_t ns);
+/* [hip only] h reads the raw local map `owner` holds, in place: several handles of one GPU that match scans against the
+ * same local map (replay harnesses: laserCloud{Corner,Surf}FromMap is one read-only cloud, mapOptimization.cpp:958-965)
+ * keep ONE copy of it in HBM, which then also stays in the 256 MB memory-side cache while every handle re-voxelises it.
+ * Each handle still builds its own downsampled map and index.  `owner` must hold a map, live on the same GPU, and must
+ * neither change its map nor be destroyed while h shares it; a later lvi_map_upload* / lvi_map_assemble on h ends the
+ * sharing (h goes back to its own memory).  The oracle copies the clouds instead (same results). */
+int32_t lvi_map_share(lvi_lidar *h, lvi_lidar *owner);
 
 /* [hip only] the whole per-scan path in one call, for replay harnesses: scan (device pointer, Msg.point_num
  * points) → organise → features → scan DS → [re-voxelise + re-index the uploaded raw map, as the reference

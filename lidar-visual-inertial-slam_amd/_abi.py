@@ -132,6 +132,7 @@ SIGNATURES = {
     "lvi_scan_match_async": (_i32, [_vp, _P(_f32), _vp]),
     "lvi_scan_upload_device": (_i32, [_vp, _vp, _i32]),
     "lvi_map_upload_device": (_i32, [_vp, _vp, _i32, _vp, _i32]),
+    "lvi_map_share": (_i32, [_vp, _vp]),
     "lvi_scan_replay_enqueue": (_i32, [_vp, _vp, _i32, _P(_f32), _vp, _i32]),
     "lvi_scan_batch_bind_device": (_i32, [_vp, _i32, _P(_vp), _P(_i32)]),
     "lvi_scan_batch_upload": (_i32, [_vp, _i32, _P(_vp), _P(_i32)]),

@@ -314,12 +314,51 @@ int32_t lvi_scan_upload_device(lvi_lidar* h, const void* d_pts, int32_t n_raw)
         return LVI_OK;
     });
 }
+// every slot of h reads the raw local map at (c, s): the handle's own memory, or another handle's (lvi_map_share)
+static void bind_raw_map(lvi_lidar* h, lvi_pt* c, lvi_pt* s)
+{
+    for (LidarDev* q : h->slots) {
+        q->mapCornerRaw = c; q->mapSurfRaw = s;
+        const VoxSegStatic st[2] = {VoxSegStatic{c, nullptr, q->mapCornerDS, q->P.mappingCornerLeafSize}, VoxSegStatic{s, nullptr, q->mapSurfDS, q->P.mappingSurfLeafSize}};
+        q->voxMap.set_static(q->ctx, st);
+    }
+}
+// a handle that shares another one's map goes back to its own memory before anything writes a raw map through it
+static void unshare_map(lvi_lidar* h)
+{
+    if (h->d.mapCornerRaw == h->d.mapCornerOwn) return;
+    join_map(h->d); sync(h->d);
+    bind_raw_map(h, h->d.mapCornerOwn, h->d.mapSurfOwn);
+    h->d.have_map_raw = false; h->d.n_map_corner = h->d.n_map_surf = 0; h->d.voxMap.bbox_cached = false;
+    for (LidarDev* q : h->slots) q->have_map = false;
+}
+
+int32_t lvi_map_share(lvi_lidar* h, lvi_lidar* owner)
+{
+    if (!h || !owner || h == owner) return fail(LVI_ERR_INVALID_ARG, "bad handles");
+    if (!owner->d.have_map_raw) return fail(LVI_ERR_STATE, "the owner holds no map");
+    if (owner->d.device != h->d.device) return fail(LVI_ERR_INVALID_ARG, "handles on different GPUs");
+    if (owner->d.mapCornerRaw != owner->d.mapCornerOwn) return fail(LVI_ERR_STATE, "the owner itself shares a map");
+    if (owner->d.n_map_corner > h->d.map_cap || owner->d.n_map_surf > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    return guarded(h, [&]() -> int32_t {
+        join_map(owner->d); sync(owner->d);                         // the owner's upload / assembly has landed
+        join_map(h->d); sync(h->d);
+        bind_raw_map(h, owner->d.mapCornerRaw, owner->d.mapSurfRaw);
+        LidarDev& d = h->d;
+        d.n_map_corner = owner->d.n_map_corner; d.n_map_surf = owner->d.n_map_surf; d.have_map_raw = true; d.voxMap.bbox_cached = false;
+        d.inc_ready = false;
+        for (LidarDev* q : h->slots) q->have_map = false;
+        return LVI_OK;
+    });
+}
+
 int32_t lvi_map_upload_device(lvi_lidar* h, const void* c, int32_t nc, const void* s, int32_t ns)
 {
     if (!h || nc < 0 || ns < 0 || (nc > 0 && !c) || (ns > 0 && !s)) return fail(LVI_ERR_INVALID_ARG, "bad map arguments");
     if (nc > h->d.map_cap || ns > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
+        unshare_map(h);
         join_map(d);
         if (nc) LVI_HIP(hipMemcpyAsync(d.mapCornerRaw, c, sizeof(lvi_pt) * (size_t)nc, hipMemcpyDeviceToDevice, d.ctx.stream));
         if (ns) LVI_HIP(hipMemcpyAsync(d.mapSurfRaw, s, sizeof(lvi_pt) * (size_t)ns, hipMemcpyDeviceToDevice, d.ctx.stream));
@@ -348,6 +387,7 @@ int32_t lvi_map_upload(lvi_lidar* h, const lvi_pt* c, int32_t nc, const lvi_pt* 
     if (nc > h->d.map_cap || ns > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
+        unshare_map(h);
         h2d(d, d.mapCornerRaw, c, (size_t)nc); h2d(d, d.mapSurfRaw, s, (size_t)ns);
         sync(d);
         d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.voxMap.bbox_cached = false; for (LidarDev* q : h->slots) q->have_map = false;
@@ -677,6 +717,7 @@ int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_key
     }
     if (tc > h->d.map_cap || ts > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
     return guarded(h, [&]() -> int32_t {
+        unshare_map(h);
         stage_map_assemble(h->d, key_indices, n_keys);                                      // extractCloud's fuse loop into the raw map (slot 0)
         stage_map_build(Slots{h->slots.data(), (int)h->slots.size()});                      // + the two VoxelGrids and the index, per slot
         return LVI_OK;

@@ -92,6 +92,7 @@ struct LidarDev {
     VoxelPlan voxScan;                                     // 2 segments (corner, surf)
     // ---- map
     lvi_pt *mapCornerRaw = nullptr, *mapSurfRaw = nullptr, *mapCornerDS = nullptr, *mapSurfDS = nullptr;
+    lvi_pt *mapCornerOwn = nullptr, *mapSurfOwn = nullptr;     // slot 0: the handle's own raw-map memory (mapCornerRaw / mapSurfRaw point elsewhere while lvi_map_share is in force)
     int n_map_corner = 0, n_map_surf = 0;
     VoxelPlan voxMap;                                      // 2 segments
     GridIndex grid[2];

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
     __shared__ int8_t s_label[FEAT_SEG_CAP + 16];
     __shared__ uint64_t s_brk[FEAT_SEG_CAP / 64 + 2];         // bit j: column jump (or cloud edge) between j-1 and j
     __shared__ unsigned short s_U[FEAT_THREADS + 4], s_L[FEAT_THREADS + 4];   // undecided / labelled bitmaps, one halfword per thread chunk (+1 pad in front)
-    __shared__ unsigned long long s_key[FEAT_SEG_CAP];        // corner candidates: (curvature bits << 32) | local index
+    __shared__ unsigned short s_cand[FEAT_SEG_CAP];           // corner candidates (local indices); their order key is (curvature bits, index)
     __shared__ unsigned short s_sorted[FEAT_SEG_CAP];         // candidates by descending key
     __shared__ int s_ws[FEAT_THREADS / 64 + 2];
     __shared__ int s_any, s_timeout;
@@ -489,16 +489,22 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
             for (int j = jlo + tid; j < jhi; j += FEAT_THREADS) mine += (s_pick[j] == 0 && s_curv[j] > a.edgeThreshold) ? 1 : 0;
             int pos = block_excl_scan<FEAT_THREADS>(mine, s_ws, &ncand);
             for (int j = jlo + tid; j < jhi; j += FEAT_THREADS)
-                if (s_pick[j] == 0 && s_curv[j] > a.edgeThreshold)
-                    s_key[pos++] = ((unsigned long long)__float_as_uint(s_curv[j]) << 32) | (unsigned)j;
+                if (s_pick[j] == 0 && s_curv[j] > a.edgeThreshold) s_cand[pos++] = (unsigned short)j;
         }
         __syncthreads();
         LVI_STAMP(1);
+        // rank = candidates with a larger (curvature bits, index) key; the keys are rebuilt from s_curv (every lane reads the
+        // same candidate at the same time: two broadcast reads) instead of being kept as 64-bit words — 64 KB of LDS less,
+        // so that a sector workgroup leaves room on its CU for the map kernels of the other scans in flight
         for (int i = tid; i < ncand; i += FEAT_THREADS) {
-            const unsigned long long mine = s_key[i];
+            const int jm = s_cand[i];
+            const unsigned long long mine = ((unsigned long long)__float_as_uint(s_curv[jm]) << 32) | (unsigned)jm;
             int rank = 0;
-            for (int q = 0; q < ncand; q++) rank += (s_key[q] > mine) ? 1 : 0;     // keys are unique (index in the low word)
-            s_sorted[rank] = (unsigned short)(mine & 0xFFFFu);
+            for (int q = 0; q < ncand; q++) {
+                const int jq = s_cand[q];
+                rank += ((((unsigned long long)__float_as_uint(s_curv[jq]) << 32) | (unsigned)jq) > mine) ? 1 : 0;     // keys are unique (index in the low word)
+            }
+            s_sorted[rank] = (unsigned short)jm;
         }
         __syncthreads();
         LVI_STAMP(2);
@@ -850,7 +856,7 @@ void layout(AR& ar, LidarDev& d)
     d.cornerDS = ar.template alloc<lvi_pt>(d.ext_cap); d.surfDS = ar.template alloc<lvi_pt>(d.ext_cap);
     d.voxScan.allocate(ar, 2, d.ext_cap, false);
     if (d.map_owner) { d.mapCornerRaw = d.map_owner->mapCornerRaw; d.mapSurfRaw = d.map_owner->mapSurfRaw; }
-    else { d.mapCornerRaw = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfRaw = ar.template alloc<lvi_pt>(d.map_cap); }
+    else { d.mapCornerRaw = d.mapCornerOwn = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfRaw = d.mapSurfOwn = ar.template alloc<lvi_pt>(d.map_cap); }
     d.mapCornerDS = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfDS = ar.template alloc<lvi_pt>(d.map_cap);
     d.voxMap.allocate(ar, 2, d.map_cap, false);
     d.voxMap.centroid_lanes = 32;

@@ -148,6 +148,10 @@ class LidarHotpath:
         self.lib.check(self.lib.dll.lvi_map_upload_device(self._h, C.c_void_p(int(d_corner)), int(nc), C.c_void_p(int(d_surf)), int(ns)),
                        "lvi_map_upload_device")
 
+    def map_share(self, owner):
+        """read `owner`'s raw local map in place (one copy per GPU; lvi_map_share)"""
+        self.lib.check(self.lib.dll.lvi_map_share(self._h, owner._h), "lvi_map_share")
+
     def scan_replay_enqueue(self, d_scan_ptr, n_raw, pose, d_record_ptr, rebuild_map=True):
         pose_c = (C.c_float * 6)(*[float(v) for v in pose])
         self.lib.check(self.lib.dll.lvi_scan_replay_enqueue(self._h, C.c_void_p(int(d_scan_ptr)), int(n_raw), pose_c,

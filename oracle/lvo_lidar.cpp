@@ -1138,6 +1138,16 @@ int32_t lvi_scan_match_async(lvi_lidar*, const float*, void*) { return fail(LVI_
 int32_t lvi_scan_upload_device(lvi_lidar*, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_scan_replay_enqueue(lvi_lidar*, const void*, int32_t, const float*, void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
 int32_t lvi_map_upload_device(lvi_lidar*, const void*, int32_t, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
+// the HIP library aliases the owner's clouds; here they are copied (the same clouds, the same results)
+int32_t lvi_map_share(lvi_lidar* h, lvi_lidar* owner)
+{
+    if (!h || !owner || h == owner) return fail(LVI_ERR_INVALID_ARG, "bad handles");
+    if (!owner->have_map_raw) return fail(LVI_ERR_STATE, "the owner holds no map");
+    if ((int)owner->mapCornerRaw.size() > h->P.max_map_points || (int)owner->mapSurfRaw.size() > h->P.max_map_points) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    h->mapCornerRaw = owner->mapCornerRaw; h->mapSurfRaw = owner->mapSurfRaw;
+    h->have_map_raw = true; h->have_map = false;
+    return LVI_OK;
+}
 int32_t lvi_prof_enable(lvi_lidar*, int32_t) { return LVI_OK; }
 int32_t lvi_prof_reset(lvi_lidar*) { return LVI_OK; }
 int32_t lvi_prof_read(lvi_lidar*, lvi_kernel_stat*, int32_t, int32_t* n) { if (n) *n = 0; return LVI_OK; }

@@ -907,6 +907,49 @@ def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
     assert frac < 0.7, frac
 
 
+def test_map_share_reads_the_owner_map_in_place(pkg, hip, scene):
+    """lvi_map_share: a second handle (also a batch handle) matches against the raw map another handle holds — same bits as
+    with its own upload; its own upload afterwards ends the sharing and leaves the owner's map alone"""
+    S = pkg.synth
+    pose = S.loop_pose(0.37, 0.01, -0.02)
+    scan = S.make_scan(20001, pose, 60)
+    guess = S.perturbed_guess(pose, 5)
+
+    def match(g):
+        g.scan_upload(scan); g.scan_organize(); g.scan_extract(); g.scan_downsample()
+        r = g.scan_match(guess)
+        return bits(r["pose"]), np.array(r["n_sel"]), r["iters"], g.counts()["map_surf_ds"]
+
+    owner = pkg.LidarHotpath(hip, **small_params())
+    owner.map_set(scene["map_corner"], scene["map_surf"])
+    ref = match(owner)
+    b = pkg.LidarHotpath(hip, **small_params())
+    with pytest.raises(Exception):
+        b.map_share(b)
+    b.map_share(owner); b.map_build()
+    got = match(b)
+    for x, y in zip(ref, got):
+        np.testing.assert_array_equal(x, y)
+    # a batch handle sharing the same map
+    bb = pkg.LidarHotpath(hip, **small_params(batch_scans=2))
+    bb.map_share(owner)
+    bb.batch_upload([scan, scan])
+    bb.batch_run(np.stack([guess, guess]), rebuild_map=True)
+    recs = bb.batch_get_records(2)
+    for z in range(2):
+        np.testing.assert_array_equal(bits(recs[z, :6]), ref[0])
+    bb.close()
+    # b uploads a different map of its own: the owner still matches against the first one
+    half_c, half_s = scene["map_corner"][: len(scene["map_corner"]) // 2], scene["map_surf"][: len(scene["map_surf"]) // 2]
+    b.map_set(half_c, half_s)
+    assert b.counts()["map_surf_ds"] < ref[3]
+    owner.map_build()
+    again = match(owner)
+    for x, y in zip(ref, again):
+        np.testing.assert_array_equal(x, y)
+    b.close(); owner.close()
+
+
 # ----------------------------------------------------------------------------- decisions on a threshold (hand-built cases)
 def test_corner_eigenvalue_ratio_gate(pkg, oracle, hip):
     """cornerOptimization accepts a line only if the largest eigenvalue of the 5-neighbour covariance exceeds 3x the second
