@@ -33,6 +33,7 @@ struct VoxArgs {
     unsigned long long* h_ncells;
     int* chunkStart; int* multiStart;                  // [nseg][VB_NB+1] exclusive scans of chunks per bin / chunks of multi-chunk bins
     int* chunkBin; int max_chunks;                     // [nseg][max_chunks]
+    int* lightBin;                                     // [nseg][VB_NB + 1]
     unsigned long long* chunkTabV; unsigned* chunkTabC; int max_multi;   // [nseg][max_multi] LDS tables of the chunks of multi-chunk bins
     int n_host[4]; int use_n_host;                     // host-known segment lengths (raw map), else dyn[].n
     const int* n_dev[4];                               // producer's device counters (scan grids), else dyn[].n
@@ -583,32 +584,38 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
     unsigned* cur = a.cursor + (size_t)s * VB_NB * VB_PAD;
     __shared__ int ws[8];
     constexpr int PER = VB_NB / 256;                    // consecutive bins per thread
-    int v[PER], sum = 0, csum = 0, msum = 0;
+    int v[PER], sum = 0, csum = 0, msum = 0, lsum = 0;
     const bool wide = a.grid[s].bin_shift > VB_CL_LOG;
+    // chunks of a bin: none for a light bin (<= VB_LIGHT points: one wavefront of vb_light_kernel takes it), else ceil(n / VB_CH)
+    auto chunks_of = [&](int n) { return wide ? (n > 0 ? 1 : 0) : (n <= VB_LIGHT ? 0 : (n + VB_CH - 1) / VB_CH); };
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         const int b = threadIdx.x * PER + j;
         v[j] = b < nbins ? (int)(a.binCountCached ? a.binCountCached[(size_t)s * VB_NB + b] : gc[(size_t)b * VB_PAD]) : 0;
         sum += v[j];
-        const int nch = wide ? (v[j] > 0) : (v[j] + VB_CH - 1) / VB_CH;
+        const int nch = chunks_of(v[j]);
         csum += nch; msum += nch > 1 ? nch : 0;
+        lsum += (!wide && v[j] > 0 && v[j] <= VB_LIGHT) ? 1 : 0;
     }
-    int tot, ctot, mtot;
+    int tot, ctot, mtot, ltot;
     int ex = block_excl_scan<256>(sum, ws, &tot);
     int cex = block_excl_scan<256>(csum, ws, &ctot);
     int mex = block_excl_scan<256>(msum, ws, &mtot);
+    int lex = block_excl_scan<256>(lsum, ws, &ltot);
     int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
     int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
+    int* lb = a.lightBin + (size_t)s * (VB_NB + 1);
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         const int b = threadIdx.x * PER + j;
         if (b < nbins) { bs[b] = ex; cur[(size_t)b * VB_PAD] = (unsigned)ex; if (!a.binCountCached) gc[(size_t)b * VB_PAD] = 0u; cs[b] = cex; ms[b] = mex; a.binVox[(size_t)s * VB_NB + b] = 0; }
         ex += v[j];
-        const int nch = wide ? (v[j] > 0) : (v[j] + VB_CH - 1) / VB_CH;
+        const int nch = chunks_of(v[j]);
         for (int q = 0; q < nch; q++) a.chunkBin[(size_t)s * a.max_chunks + cex + q] = b;
         cex += nch; mex += nch > 1 ? nch : 0;
+        if (!wide && v[j] > 0 && v[j] <= VB_LIGHT) lb[lex++] = b;
     }
-    if (threadIdx.x == 0) { bs[nbins] = tot; cs[nbins] = ctot; ms[nbins] = mtot; }
+    if (threadIdx.x == 0) { bs[nbins] = tot; cs[nbins] = ctot; ms[nbins] = mtot; lb[VB_NB] = ltot; }
 }
 
 __global__ __launch_bounds__(256) void vb_scatter_kernel(Batch<VoxArgs> B_)
@@ -724,6 +731,76 @@ __device__ __forceinline__ int vb_emit(const VbCells& L, const VoxGrid& g, lvi_p
     return tot;
 }
 
+// Light bins (<= VB_LIGHT points; the ring and scan grids consist of them, and so does the corner map): ONE wavefront per bin,
+// four bins in flight per workgroup, no workgroup barrier.  The occupied cells of the bin are a 1024-bit set; a cell's rank in
+// that set is its slot in a compact table (<= VB_LIGHT slots) and its position in the output, so nothing is zeroed, scanned
+// or compacted beyond the cells that hold points (a 1024-cell table per 40-point bin was 34 us for a 100 k-point ring grid).
+struct VbLight {
+    unsigned long long bm[16]; unsigned base[16];
+    unsigned long long sx[VB_LIGHT], sy[VB_LIGHT], sz[VB_LIGHT], si[VB_LIGHT];
+    unsigned cn[VB_LIGHT]; unsigned short cell[VB_LIGHT];
+};
+// LDS written by some lanes of a wavefront is read by others: order the accesses (a wavefront's LDS operations complete in order)
+__device__ __forceinline__ void wave_lds_sync() { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+
+// (the second role of the workgroups of vb_accum_kernel: called by all 256 threads, after a workgroup barrier)
+__device__ __forceinline__ void vb_light_items(const VoxArgs& a, int s, const VoxGrid& g, VbLight* LW)
+{
+    const int sh = g.bin_shift;
+    if (sh > VB_CL_LOG) return;
+    const int* lb = a.lightBin + (size_t)s * (VB_NB + 1);
+    const int nl = lb[VB_NB];
+    const int wv = threadIdx.x >> 6, ln = lane_id();
+    VbLight& L = LW[wv];
+    const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
+    const lvi_pt* __restrict__ pts = a.bucketed + (size_t)s * a.seg_cap;
+    lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
+    uint2* __restrict__ skc = a.stagingKC + (size_t)s * a.seg_cap;
+    constexpr int PP = VB_LIGHT / 64;                   // points per lane
+    for (int item = blockIdx.x * 4 + wv; item < nl; item += gridDim.x * 4) {
+        const int b = lb[item];
+        const int p0 = bs[b], p1 = bs[b + 1];
+        const unsigned kbase = (unsigned)b << sh;
+        if (ln < 16) L.bm[ln] = 0ull;
+        wave_lds_sync();
+        lvi_pt p[PP]; unsigned c[PP]; bool ok[PP];
+#pragma unroll
+        for (int u = 0; u < PP; u++) { const int i = p0 + ln + 64 * u; ok[u] = i < p1; if (ok[u]) p[u] = pts[i]; }
+#pragma unroll
+        for (int u = 0; u < PP; u++) {
+            c[u] = 0u;
+            if (ok[u]) { c[u] = (vox_key_of_pt(g, p[u]) - kbase) & (unsigned)(VB_TAB - 1); atomicOr(&L.bm[c[u] >> 6], 1ull << (c[u] & 63u)); }
+        }
+        wave_lds_sync();
+        const int pc = ln < 16 ? __popcll(L.bm[ln]) : 0;
+        const int incl = wave_incl_scan(pc);
+        if (ln < 16) L.base[ln] = (unsigned)(incl - pc);
+        const int nd = __shfl(incl, 15, 64);            // occupied cells of the bin (<= its points <= VB_LIGHT)
+        for (int r = ln; r < nd; r += 64) { L.sx[r] = 0ull; L.sy[r] = 0ull; L.sz[r] = 0ull; L.si[r] = 0ull; L.cn[r] = 0u; }
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < PP; u++) {
+            if (!ok[u]) continue;
+            const unsigned w = c[u] >> 6;
+            const int slot = (int)L.base[w] + __popcll(L.bm[w] & ((1ull << (c[u] & 63u)) - 1ull));
+            int cell[3];
+            vox_cell_abs(g, p[u], cell);
+            atomicAdd(&L.sx[slot], fx_xyz(p[u].x, cell[0], g.leaf_d, g.fx_k)); atomicAdd(&L.sy[slot], fx_xyz(p[u].y, cell[1], g.leaf_d, g.fx_k));
+            atomicAdd(&L.sz[slot], fx_xyz(p[u].z, cell[2], g.leaf_d, g.fx_k)); atomicAdd(&L.si[slot], fx_int(p[u].intensity, g.fx_ki));
+            atomicAdd(&L.cn[slot], 1u);
+            L.cell[slot] = (unsigned short)c[u];        // every point of the cell writes the same value
+        }
+        wave_lds_sync();
+        for (int r = ln; r < nd; r += 64) {
+            const unsigned key = kbase + (unsigned)L.cell[r];
+            const unsigned m = L.cn[r];
+            stg[p0 + r] = fx_centroid(g, key, L.sx[r], L.sy[r], L.sz[r], L.si[r], m); skc[p0 + r] = make_uint2(key, m);
+        }
+        if (ln == 0) a.binVox[(size_t)s * VB_NB + b] = nd;
+        wave_lds_sync();
+    }
+}
+
 // One workgroup per chunk of <= VB_CH bucketed points of one bin.  A bin that is a single chunk is finished here;
 // the chunks of a larger bin leave their LDS tables in chunkTab and vb_merge adds them up (no global atomics,
 // so a bin with 10^5 points is spread over 25 workgroups instead of keeping one busy for 0.2 ms).
@@ -735,9 +812,11 @@ __global__ __launch_bounds__(NT) void vb_accum_kernel(Batch<VoxArgs> B_)
     const VoxGrid& g = a.grid[s];
     const int nbins = g.nbins, sh = g.bin_shift;
     if (nbins == 0) return;
-    __shared__ VbCells L;
+    union Lds { struct { VbCells L; unsigned short cl[1 << VB_CL_LOG]; } c; VbLight w[4]; };
+    __shared__ Lds U;                                                       // chunk role: table + vb_emit's list of occupied cells; light role: 4 wavefront tables
+    VbCells& L = U.c.L;
+    unsigned short* cl = U.c.cl;
     __shared__ unsigned occ[32];                                            // occupied sub-ranges of a wide bin, one bit each
-    __shared__ unsigned short cl[1 << VB_CL_LOG];                           // vb_emit's list of occupied cells
     static_assert(VB_NB == 4096 && VB_CL_LOG == 10, "occ[] is sized for 2^32 / VB_NB / 2^VB_CL_LOG sub-ranges");
     __shared__ int ws[NT / 64 + 1];
     const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
@@ -802,6 +881,9 @@ __global__ __launch_bounds__(NT) void vb_accum_kernel(Batch<VoxArgs> B_)
             __syncthreads();
         }
     }
+    // second role: the light bins of the segment, one wavefront each
+    __syncthreads();
+    if constexpr (NT == 256) vb_light_items(a, s, g, U.w);
 }
 
 // bins of more than one chunk: add the chunk tables up and emit
@@ -818,6 +900,7 @@ __global__ __launch_bounds__(256) void vb_merge_kernel(Batch<VoxArgs> B_)
     const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
     const int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
     const int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
+    if (ms[nbins] == 0) return;                                             // no bin of this segment has more than one chunk (ring / scan grids)
     lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
     uint2* __restrict__ skc = a.stagingKC + (size_t)s * a.seg_cap;
     const int cells = 1 << sh;
@@ -942,7 +1025,7 @@ static VoxArgs make_args(const VoxelPlan& p)
     return VoxArgs{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
                    p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm,
                    p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
-                   p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
+                   p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_lightBin, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
                    {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0,
                    {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max, (p.bbox_cached && p.hist_cached) ? p.d_binCountCached : nullptr, p.d_wprefix};
 }
@@ -1285,8 +1368,8 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
     const VoxArgs& a = B.a[0];
     char nm[16][48];
     const char* base[16] = {"vox_minmax", "vox_setup", "vox_keys", "vox_heads_count", "vox_heads_scan", "vox_heads_assign", "vox_centroid",
-                            "vb_hist", "vb_scan", "vb_scatter", "vb_accum", "vb_outscan", "vb_copy", "vb_merge", "", ""};
-    for (int i = 0; i < 14; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
+                            "vb_hist", "vb_scan", "vb_scatter", "vb_accum", "vb_outscan", "vb_copy", "vb_merge", "vb_light", ""};
+    for (int i = 0; i < 15; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
     // the bbox pass is skipped when every plan of the batch holds the partial records of its (unchanged) input: the raw
     // local map gets them where its points are touched anyway — upload / assembly — instead of once per re-voxelisation
     bool cached = true;

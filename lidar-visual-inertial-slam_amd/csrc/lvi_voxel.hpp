@@ -45,6 +45,7 @@ constexpr int VB_STILE = 4096;   // binned path: points per workgroup of the sca
 constexpr int VB_PAD = 1;        // binned path: stride of the global bin counters / cursors (one per 64-B line, VB_PAD = 16, measured SLOWER: hist 36 vs 29 us, scatter 67 vs 56 us)
 constexpr int VB_WG = 512;       // deterministic partition: workgroups (= contiguous point ranges) per segment (256 / 512 / 1024: scatter 62 / 44 / 46 us on the 4.87 M-point map)
 constexpr int VB_CH = 4096;      // binned path: points per accumulate workgroup (chunk of a bin)
+constexpr int VB_LIGHT = 256;     // binned path: a bin of at most this many points is accumulated by ONE wavefront (vb_light_kernel)
 constexpr int VB_TAB = 1 << VB_CL_LOG;      // entries per compacted chunk table
 constexpr int VB_TABC = VB_TAB + 32;         // u32 words per chunk table: entries, then the entry count
 constexpr int VB_ACC_BLOCKS = 1024;
@@ -80,6 +81,7 @@ struct VoxelPlan {
     int* d_chunkStart = nullptr;      // [nseg][VB_NB+1]  exclusive scan of the chunks per bin
     int* d_multiStart = nullptr;      // [nseg][VB_NB+1]  … of the chunks of bins with more than one chunk
     int* d_chunkBin = nullptr;        // [nseg][max_chunks] bin of every chunk (saves the accumulate kernel a 12-step search through L2)
+    int* d_lightBin = nullptr;        // [nseg][VB_NB + 1] bins of at most VB_LIGHT points (one wavefront each, vb_light_kernel); their number at [VB_NB]
     int max_chunks = 0;
     unsigned long long* d_chunkTabV = nullptr;   // [nseg][max_multi][4][VB_TAB] compacted chunk tables of multi-chunk bins (sums of the occupied cells)
     unsigned* d_chunkTabC = nullptr;             // [nseg][max_multi][VB_TABC]: (cell << 16 | count) per entry, entry count at [VB_TAB]
@@ -119,6 +121,7 @@ struct VoxelPlan {
         d_multiStart = ar.template alloc<int>((size_t)nseg_ * (VB_NB + 1));
         max_chunks = div_up(seg_cap_, VB_CH) + VB_NB;
         d_chunkBin = ar.template alloc<int>((size_t)nseg_ * max_chunks);
+        d_lightBin = ar.template alloc<int>((size_t)nseg_ * (VB_NB + 1));
         max_multi = 2 * div_up(seg_cap_, VB_CH) + 2;         // sum of ceil(cnt/CH) over bins with cnt > CH  <=  2 n / CH
         d_chunkTabV = ar.template alloc<unsigned long long>((size_t)nseg_ * max_multi * (4 * VB_TAB));
         d_chunkTabC = ar.template alloc<unsigned>((size_t)nseg_ * max_multi * VB_TABC);
