@@ -34,6 +34,7 @@ struct VoxArgs {
     int* chunkStart; int* multiStart;                  // [nseg][VB_NB+1] exclusive scans of chunks per bin / chunks of multi-chunk bins
     int* chunkBin; int max_chunks;                     // [nseg][max_chunks]
     int* lightBin;                                     // [nseg][VB_NB + 1]
+    int* multiOwner;                                   // [nseg][max_multi] chunk-table slot -> its bin if the slot is the bin's first, else -1
     unsigned long long* chunkTabV; unsigned* chunkTabC; int max_multi;   // [nseg][max_multi] LDS tables of the chunks of multi-chunk bins
     int n_host[4]; int use_n_host;                     // host-known segment lengths (raw map), else dyn[].n
     const int* n_dev[4];                               // producer's device counters (scan grids), else dyn[].n
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
         ex += v[j];
         const int nch = chunks_of(v[j]);
         for (int q = 0; q < nch; q++) a.chunkBin[(size_t)s * a.max_chunks + cex + q] = b;
+        if (nch > 1) for (int q = 0; q < nch; q++) a.multiOwner[(size_t)s * a.max_multi + mex + q] = q == 0 ? b : -1;
         cex += nch; mex += nch > 1 ? nch : 0;
         if (!wide && v[j] > 0 && v[j] <= VB_LIGHT) lb[lex++] = b;
     }
@@ -900,13 +902,16 @@ __global__ __launch_bounds__(256) void vb_merge_kernel(Batch<VoxArgs> B_)
     const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
     const int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
     const int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
-    if (ms[nbins] == 0) return;                                             // no bin of this segment has more than one chunk (ring / scan grids)
+    const int mtot = ms[nbins];                                             // chunk tables of this segment: none for the ring / scan grids
     lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
     uint2* __restrict__ skc = a.stagingKC + (size_t)s * a.seg_cap;
     const int cells = 1 << sh;
-    for (int b = blockIdx.x; b < nbins; b += gridDim.x) {
+    // one workgroup per multi-chunk bin, found through its first chunk-table slot (at most n / VB_CH such bins exist: the grid
+    // is sized for that, not for the bins — every workgroup of this kernel needs 39 KB of LDS just to start)
+    for (int t = blockIdx.x; t < mtot; t += gridDim.x) {
+        const int b = a.multiOwner[(size_t)s * a.max_multi + t];
+        if (b < 0) continue;
         const int nch = cs[b + 1] - cs[b];
-        if (nch <= 1) continue;
         const size_t t0 = (size_t)s * a.max_multi + ms[b];
         vb_zero(L, cells);
         // wavefront w adds chunks w, w + 4, ...: entries of one chunk name distinct cells, chunks meet through LDS atomics;
@@ -1025,7 +1030,7 @@ static VoxArgs make_args(const VoxelPlan& p)
     return VoxArgs{p.d_static, p.d_dyn, p.d_grid, p.d_n, p.d_nbits, p.sort.keysA, p.sort.valsA, p.sort.keysB, p.sort.valsB,
                    p.d_blockHeads, p.d_starts, p.d_nout, p.nseg, p.seg_cap, p.nblk_h, p.concat_out ? 1 : 0, p.d_mmPartial, p.nblk_mm,
                    p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
-                   p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_lightBin, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
+                   p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_lightBin, p.d_multiOwner, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
                    {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0,
                    {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max, (p.bbox_cached && p.hist_cached) ? p.d_binCountCached : nullptr, p.d_wprefix};
 }
@@ -1394,7 +1399,7 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
         const dim3 ga(std::max(64, std::min(2 * div_up(p.seg_cap, VB_CH) + 64, 2048)), p.nseg, S);
         // 256 threads: 128 / 512 / 1024 measured 172 / 163 / 231 us instead of 136 for four slots of the 4.87 M-point map
         LVI_LAUNCH(ctx, nm[10], 16.0 * n_hint, hipLaunchKernelGGL(vb_accum_kernel<256>, ga, dim3(256), 0, ctx.stream, B));
-        LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, gb, dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[13], 0, hipLaunchKernelGGL(vb_merge_kernel, dim3(std::max(1, std::min(p.max_multi, VB_ACC_BLOCKS)), p.nseg, S), dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[11], 0, hipLaunchKernelGGL(vb_outscan_kernel, dim3(1, 1, S), dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[12], 0, hipLaunchKernelGGL(vb_copy_kernel, gb, dim3(256), 0, ctx.stream, B));
         return;

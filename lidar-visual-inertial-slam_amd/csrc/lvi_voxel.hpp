@@ -81,6 +81,7 @@ struct VoxelPlan {
     int* d_chunkStart = nullptr;      // [nseg][VB_NB+1]  exclusive scan of the chunks per bin
     int* d_multiStart = nullptr;      // [nseg][VB_NB+1]  … of the chunks of bins with more than one chunk
     int* d_chunkBin = nullptr;        // [nseg][max_chunks] bin of every chunk (saves the accumulate kernel a 12-step search through L2)
+    int* d_multiOwner = nullptr;      // [nseg][max_multi] first chunk-table slot of a multi-chunk bin -> the bin (else -1)
     int* d_lightBin = nullptr;        // [nseg][VB_NB + 1] bins of at most VB_LIGHT points (one wavefront each, vb_light_kernel); their number at [VB_NB]
     int max_chunks = 0;
     unsigned long long* d_chunkTabV = nullptr;   // [nseg][max_multi][4][VB_TAB] compacted chunk tables of multi-chunk bins (sums of the occupied cells)
@@ -123,6 +124,7 @@ struct VoxelPlan {
         d_chunkBin = ar.template alloc<int>((size_t)nseg_ * max_chunks);
         d_lightBin = ar.template alloc<int>((size_t)nseg_ * (VB_NB + 1));
         max_multi = 2 * div_up(seg_cap_, VB_CH) + 2;         // sum of ceil(cnt/CH) over bins with cnt > CH  <=  2 n / CH
+        d_multiOwner = ar.template alloc<int>((size_t)nseg_ * max_multi);
         d_chunkTabV = ar.template alloc<unsigned long long>((size_t)nseg_ * max_multi * (4 * VB_TAB));
         d_chunkTabC = ar.template alloc<unsigned>((size_t)nseg_ * max_multi * VB_TABC);
     }
