@@ -7,9 +7,9 @@ COMMON="--steps 12 --warmup 3 --repeats 1 --no-cpu --no-tracker --profile-steps 
 rocprofv3 --kernel-trace --output-format csv -d $O/b1 -- python3 bench.py $COMMON --inflight 1 --batch 1 > $O/b1.json 2> $O/b1.err
 python3 tools/summarize_prof.py steady $O/b1 $O/r02_rocprof_steady_B1.md 8 > /dev/null
 echo "steady B1 done"
-rocprofv3 --kernel-trace --output-format csv -d $O/b44 -- python3 bench.py $COMMON --inflight 4 --batch 4 > $O/b44.json 2> $O/b44.err
-python3 tools/summarize_prof.py steady $O/b44 $O/r02_rocprof_steady_4x4.md 24 > /dev/null
-echo "steady 4x4 done"
+rocprofv3 --kernel-trace --output-format csv -d $O/b44 -- python3 bench.py $COMMON --inflight 4 --batch 8 > $O/b44.json 2> $O/b44.err
+python3 tools/summarize_prof.py steady $O/b44 $O/r02_rocprof_steady_4x8.md 12 > /dev/null
+echo "steady 4x8 done"
 PM="--steps 4 --warmup 2 --repeats 1 --no-cpu --no-tracker --profile-steps 0 --prime-steps 0 --sequential-scans 0 --inflight 1 --batch 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -- python3 bench.py $PM > $O/pf.json 2> $O/pf.err
 echo "pmc fetch done"
