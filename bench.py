@@ -348,9 +348,9 @@ def main():
     if with_bytes:
         # dominant kernel = largest total time per step among the kernels of the path
         roofline = roof(with_bytes[0], "HIP events on the launch stream of one of the handles, profiled pass of the same workload right "
-                                       "after the timed windows; the kernel with the largest total time per step.  icp_residual is VALU-issue "
-                                       "bound on an index that stays in L2 (clock64 phase stamps, DESIGN.md 5): its HBM fraction is small by "
-                                       "construction; bytes = 128 B x the real query count read back from the device")
+                                       "after the timed windows; the kernel with the largest total time per step.  icp_residual is a chain of "
+                                       "dependent gathers on L2s that every launch finds cold (clock64 phase stamps, DESIGN.md 5), neither HBM- nor "
+                                       "VALU-bound: its HBM fraction is small by construction; bytes = 128 B x the real query count read back from the device")
         stream = max(with_bytes, key=lambda s: s["bytes_alg"] / s["launches"] if s["avg_us"] > 0 else 0)
         big = [s for s in with_bytes if s["bytes_alg"] / s["launches"] >= 0.5 * stream["bytes_alg"] / stream["launches"]]
         roofline_bw = roof(max(big, key=lambda s: s["total_ms"]), "the HBM-streaming kernel with the largest total time (map re-voxelisation)")
@@ -565,7 +565,31 @@ def bench_tracker(pkg, hip, device, rank, world, seconds):
         if it >= warm and t_total >= seconds and n_done >= 40:
             break
     xy, st, _ = t.get_lk()
-    rate = n_done / t_total
+    rate_one = n_done / t_total
+    # the same with three frame sequences in flight (own handle and stream each, as the lidar leg keeps several scans in flight):
+    # a handle is synchronised only right before it receives its next frame, so upload, pyramid and LK of different sequences overlap
+    ts = [t] + [pkg.TrackerHotpath(hip, device=device, max_width=w, max_height=h) for _ in range(2)]
+    for q in ts[1:]:
+        q.push_image(frames[0])
+    for q in ts:
+        q.sync()
+    n_pipe, it2 = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        q = ts[it2 % len(ts)]
+        q.sync()
+        q.push_image(frames[(mine[(it2 // len(ts)) % len(mine)] + 1) % n_frames]); q.set_points(pts); q.run_lk()
+        it2 += 1
+        if it2 % 30 == 0 and time.perf_counter() - t0 >= seconds and it2 >= 120:
+            break
+    for q in ts:
+        q.sync()
+    t_pipe = time.perf_counter() - t0
+    n_pipe = it2
+    xy2, st2, _ = ts[1].get_lk()
+    rate = n_pipe / t_pipe
+    for q in ts[1:]:
+        q.close()
     # Shi-Tomasi on the current frame (goodFeaturesToTrack, 150 corners, no mask), device-resident image
     t.set_mask(None); t.run_gftt(150); t.sync()
     t0 = time.perf_counter()
@@ -616,8 +640,11 @@ def bench_tracker(pkg, hip, device, rank, world, seconds):
         return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 5), bytes_alg=nbytes,
                     kernel_us=round(us, 1), note=note)
     return dict(metric="lk_frames_per_sec_1280x720_150pts", value=round(total_rate, 1), unit="frames/s", per_rank=[round(r, 1) for r in per_rank],
-                frames_timed=n_done, seconds_timed=round(t_total, 3), sharding="frame pair i -> rank i mod world",
-                tracked=int(st.sum()), features=int(len(pts)), note="includes the H2D of each new 0.92 MB frame", gftt_us_per_frame=round(gftt_us, 1),
+                frames_timed=n_pipe, seconds_timed=round(t_pipe, 3), sharding="frame pair i -> rank i mod world",
+                tracked=int(min(st.sum(), st2.sum())), features=int(len(pts)),
+                note="three frame sequences in flight (own handle and stream each); includes the H2D of each new 0.92 MB frame",
+                one_sequence=dict(frames_per_sec=round(rate_one, 1), note="one handle, host waits for every frame: the latency of upload + pyramid + LK + sync"),
+                gftt_us_per_frame=round(gftt_us, 1),
                 us_per_frame=dict(push_image=round(1e6 * parts[0] / n_done, 1), set_points=round(1e6 * parts[1] / n_done, 1), lk_and_sync=round(1e6 * parts[2] / n_done, 1)),
                 kernel_us_per_frame={k: round(v, 2) for k, v in sorted(kt.items(), key=lambda kv: -kv[1])}, node_callback=node_fps,
                 roofline_lk=rl(lk_bytes, lk_us, "SURVEY 8(d): 2.1 MB per LK frame pair / sum of the pyramid + LK kernel times (HIP events): latency-bound, 150 wavefronts"),

@@ -564,12 +564,16 @@ __device__ __forceinline__ void lm_row(const float tr[6], const lvi_pt& ori, con
 constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup (64: the residual phase fills its wavefront)
 static_assert(ICP_QPB <= 64, "the residual phase runs on one wavefront");
 
-// Two phases per workgroup of 64 features:
-//   A  all 512 threads: transform + 5-NN, 8 lanes per feature; the merged neighbour lists go to LDS
+// Three phases per workgroup of 64 features (64 G threads):
+//   0  first wavefront, one lane per feature: the skip test of the 5-NN search (see below); the features that search are listed
+//   A  G lanes per LISTED feature, packed to the front of the workgroup: transform + 5-NN; the merged neighbour lists go to LDS
 //   B  ONE wavefront, one lane per feature: line / plane fit, residual, Gauss-Newton row (6+1 values) and its
-//      27 products in f64, into LDS; then 28 threads add the 32 rows in fixed order → one partial per workgroup.
-// (Doing B inside the 8-lane groups made every wavefront execute the whole eigen/QR code for 8 active lanes;
-// the kernel is VALU-issue bound, ~2500 instructions per lane, not latency bound: half-filled wavefronts in B cost.)
+//      27 products in f64, into LDS; then 28 threads add the 64 rows in fixed order → one partial per workgroup.
+// (Doing B inside the G-lane groups made every wavefront execute the whole eigen/QR code for a few active lanes.)
+// What a launch costs (clock64 stamps, one scan, Q = 22.6 k): a workgroup needs ~13 k cycles (6 us) when its features skip the
+// search and ~28 k when they all search, of a 20 us launch: every launch starts on cold L2s (a kernel boundary on this
+// multi-XCD part invalidates them: the counters show the 1.9 MB index re-fetched by every launch) and the phases are chains
+// of dependent gathers.  The chip's VALU issue capacity is not the limit (~3 k wave-instructions x 353 workgroups = 2 us of it).
 template <int G, int KB>
 __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
 {

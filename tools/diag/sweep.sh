@@ -1,6 +1,8 @@
 #!/bin/bash
-run() { env $1 python bench.py $2 --no-cpu --no-tracker --steps 20 --repeats 3 --profile-steps 0 --sequential-scans 0 > /tmp/sw.json 2>/tmp/sw.err || tail -3 /tmp/sw.err; python -c "
+# env-knob sweep on the headline configuration (GPU box): bash tools/diag/sweep.sh "VAR=a" "VAR=b" ...
+for kv in "$@"; do
+  env $kv python bench.py --no-cpu --no-tracker --sequential-scans 0 --repeats 3 --profile-steps 0 > gpurun_out/sw.json 2> gpurun_out/sw.err || tail -3 gpurun_out/sw.err
+  python -c "
 import json
-d=json.load(open('/tmp/sw.json')); print('$1 | $2 ->', d['value_windows']['scans_per_sec']['all'], d['results_ok'])"; }
-run "X=1" "--batch 4 --inflight 4"
-run "LVI_EXPERIMENT_EXTRA_LAUNCH=1" "--batch 4 --inflight 4"
+d=json.load(open('gpurun_out/sw.json')); print('%-28s' % '$kv', d['value_windows']['scans_per_sec']['all'], d['results_ok'])"
+done
