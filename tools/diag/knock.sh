@@ -9,3 +9,8 @@ run "--icp-iters 5"
 run "--icp-iters 1"
 run "--frozen-map --icp-iters 1"
 run "--map-source assemble"
+run "--batch 4 --inflight 4"
+run "--batch 1 --inflight 4"
+run "--batch 1 --inflight 1"
+run "--batch 8 --inflight 2"
+run "--no-share-map"
