@@ -429,3 +429,27 @@ def test_batch_entry_points_are_a_loop(pkg, oracle):
     with pytest.raises(pkg.LviError):
         h.batch_upload(scans + scans)
     h.close()
+
+
+def test_map_share_is_the_owners_map(pkg, oracle):
+    """lvi_map_share on the oracle: the sharing handle matches against the owner's clouds (copied here, aliased on the GPU)"""
+    from helpers import make_small_scene, small_params
+    S = pkg.synth
+    sc = make_small_scene(pkg, oracle, n_raw=6001, n_kf=5, Horizon_SCAN=2048)
+    P = small_params(Horizon_SCAN=2048, max_raw_points=8192, icp_max_iters=6, icp_disable_break=1)
+    pose = S.loop_pose(0.37)
+    scan, guess = S.make_scan(6001, pose, 70), S.perturbed_guess(pose, 1)
+    a, b = pkg.LidarHotpath(oracle, **P), pkg.LidarHotpath(oracle, **P)
+    with pytest.raises(pkg.LviError):
+        b.map_share(a)                                                 # the owner holds no map yet
+    a.map_upload(sc["map_corner"], sc["map_surf"]); a.map_build()
+    b.map_share(a); b.map_build()
+    res = []
+    for h in (a, b):
+        h.scan_upload(scan); h.scan_organize(); h.scan_extract(); h.scan_downsample()
+        res.append(h.scan_match(guess))
+    np.testing.assert_array_equal(res[0]["pose"], res[1]["pose"])
+    assert a.counts()["map_surf_ds"] == b.counts()["map_surf_ds"] > 0
+    with pytest.raises(pkg.LviError):
+        a.map_share(a)
+    a.close(); b.close()
