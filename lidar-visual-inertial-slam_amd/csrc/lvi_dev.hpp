@@ -128,6 +128,26 @@ __device__ __forceinline__ T wave_sum(T v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// 64-bit integer sum over the wavefront through DPP moves (quad swaps, half-row and row mirrors, row broadcasts) instead of
+// twelve ds_bpermute round trips: every lane receives the total.  Integer addition commutes: the same value as wave_sum.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_move_i64(long long v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v)
+{
+    v += dpp_move_i64<0xB1, 0xF>(v);              // quad_perm [1,0,3,2]
+    v += dpp_move_i64<0x4E, 0xF>(v);              // quad_perm [2,3,0,1]: every lane holds its quad's sum
+    v += dpp_move_i64<0x141, 0xF>(v);             // row_half_mirror: ... its half row's
+    v += dpp_move_i64<0x140, 0xF>(v);             // row_mirror: ... its row's (16 lanes)
+    v += dpp_move_i64<0x142, 0xA>(v);             // row_bcast15 into rows 1 and 3
+    v += dpp_move_i64<0x143, 0xC>(v);             // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 __device__ __forceinline__ float wave_min(float v)
 {
 #pragma unroll

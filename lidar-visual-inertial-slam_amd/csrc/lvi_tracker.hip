@@ -173,11 +173,21 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
     constexpr int NPX = (LK_WIN_MAX * LK_WIN_MAX + 63) / 64;   // 7 window pixels per lane
     __shared__ uint8_t sI[TW * TW];
     __shared__ short sD[DW * DW * 2];
-    __shared__ uint8_t sJ[DW * DW];
+    // target image: a region of JW x JW pixels around the window stays in LDS across the iterations of a level (the window moves
+    // by a fraction of a pixel per iteration: reloading its 22 x 22 tile from L2 every iteration was most of the kernel's 80 us)
+    constexpr int JR = 8, JW = DW + 2 * JR;
+    __shared__ uint8_t sJ[JW * JW];
+    int jx0 = 0, jy0 = 0; bool jvalid = false;     // absolute coordinates of sJ[0] in the level (uniform over the wavefront)
     const int f = blockIdx.x, l = threadIdx.x;
     if (f >= a.n) return;
     const int win = a.win;
     const float halfWin = (win - 1) * 0.5f;
+    // window pixels of this lane, (row, column), once: `win` is a run-time value and an integer division costs ~40 instructions
+    // (lanes beyond the window take pixel (0, 0) and are masked out: no branch inside the pixel loops, so that the LDS reads
+    // of all seven pixels are in flight together — one wavefront per workgroup has nothing else to hide their latency)
+    int wy[NPX], wx[NPX]; bool wv[NPX];
+#pragma unroll
+    for (int j = 0; j < NPX; j++) { const int p = l + 64 * j; wv[j] = p < win * win; wy[j] = wv[j] ? p / win : 0; wx[j] = wv[j] ? p - wy[j] * win : 0; }
     const float px0 = a.prev_xy[2 * f], py0 = a.prev_xy[2 * f + 1];
     float outx = 0.f, outy = 0.f, errv = 0.f;
     bool st = true;
@@ -186,6 +196,39 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
 
     for (int level = a.max_level; level >= 0; level--) {
         const Level I = a.prev.lv[level], J = a.next.lv[level];
+        jvalid = false;
+        // make the window [inx, inx + DW) x [iny, iny + DW) of the target level resident; returns the offset of its corner in sJ
+        constexpr int NJ = (JW * JW + 63) / 64;
+        // all loads of a lane are issued before the first one is stored (a loop of load, wait, store was 23 round trips to L2)
+        auto region_issue = [&](int x0, int y0, uint8_t (&rj)[NJ]) {
+            if (x0 >= 0 && y0 >= 0 && x0 + JW <= J.w && y0 + JW <= J.h) {                  // interior: no border arithmetic
+                const uint8_t* __restrict__ src = J.px + (size_t)y0 * J.w + x0;
+#pragma unroll
+                for (int k = 0; k < NJ; k++) { const int t = l + 64 * k, ty = t / JW, tx = t - ty * JW; rj[k] = t < JW * JW ? src[ty * J.w + tx] : (uint8_t)0; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NJ; k++) {
+                    const int t = l + 64 * k, ty = t / JW, tx = t - ty * JW;
+                    rj[k] = t < JW * JW ? J.px[(size_t)reflect101(y0 + ty, J.h) * J.w + reflect101(x0 + tx, J.w)] : (uint8_t)0;
+                }
+            }
+        };
+        auto region_commit = [&](int x0, int y0, const uint8_t (&rj)[NJ]) {
+#pragma unroll
+            for (int k = 0; k < NJ; k++) { const int t = l + 64 * k; if (t < JW * JW) sJ[t] = rj[k]; }
+            jx0 = x0; jy0 = y0; jvalid = true;
+        };
+        // make the window [inx, inx + DW) x [iny, iny + DW) of the target level resident; returns the offset of its corner in sJ
+        auto target_window = [&](int inx, int iny) {
+            if (!(jvalid && inx >= jx0 && inx + DW <= jx0 + JW && iny >= jy0 && iny + DW <= jy0 + JW)) {
+                __syncthreads();
+                uint8_t rj[NJ];
+                region_issue(inx - JR, iny - JR, rj);
+                region_commit(inx - JR, iny - JR, rj);
+                __syncthreads();
+            }
+            return (iny - jy0) * JW + (inx - jx0);
+        };
         float prevx = px0 * (float)(1. / (1 << level)), prevy = py0 * (float)(1. / (1 << level));
         float nextx, nexty;
         if (level == a.max_level) { nextx = prevx; nexty = prevy; }
@@ -199,22 +242,40 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
         }
         // ---- stage the source tile (REFLECT_101 border of the pyramid level) and its Scharr derivatives
         __syncthreads();
-        for (int t = l; t < TW * TW; t += 64) {
-            const int ty = t / TW, tx = t - ty * TW;
-            sI[t] = I.px[(size_t)reflect101(ipy - 1 + ty, I.h) * I.w + reflect101(ipx - 1 + tx, I.w)];
+        {
+            constexpr int NI = (TW * TW + 63) / 64;
+            uint8_t ri[NI];
+            if (ipx >= 1 && ipy >= 1 && ipx - 1 + TW <= I.w && ipy - 1 + TW <= I.h) {      // interior: no border arithmetic
+                const uint8_t* __restrict__ src = I.px + (size_t)(ipy - 1) * I.w + (ipx - 1);
+#pragma unroll
+                for (int k = 0; k < NI; k++) { const int t = l + 64 * k, ty = t / TW, tx = t - ty * TW; ri[k] = t < TW * TW ? src[ty * I.w + tx] : (uint8_t)0; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NI; k++) {
+                    const int t = l + 64 * k, ty = t / TW, tx = t - ty * TW;
+                    ri[k] = t < TW * TW ? I.px[(size_t)reflect101(ipy - 1 + ty, I.h) * I.w + reflect101(ipx - 1 + tx, I.w)] : (uint8_t)0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NI; k++) { const int t = l + 64 * k; if (t < TW * TW) sI[t] = ri[k]; }
         }
         __syncthreads();
-        for (int t = l; t < DW * DW; t += 64) {
-            const int dy_ = t / DW, dx_ = t - dy_ * DW;
-            const int X = ipx + dx_, Y = ipy + dy_;
-            short gx = 0, gy = 0;
-            if (X >= 0 && X < I.w && Y >= 0 && Y < I.h) {     // the derivative image is zero outside the level
+        {
+            constexpr int ND = (DW * DW + 63) / 64;
+            short gxs[ND], gys[ND];
+#pragma unroll
+            for (int k = 0; k < ND; k++) {
+                const int t = min(l + 64 * k, DW * DW - 1);
+                const int dy_ = t / DW, dx_ = t - dy_ * DW;
+                const int X = ipx + dx_, Y = ipy + dy_;
                 const uint8_t* c = &sI[(dy_ + 1) * TW + (dx_ + 1)];
                 const int p00 = c[-TW - 1], p01 = c[-TW], p02 = c[-TW + 1], p10 = c[-1], p12 = c[1], p20 = c[TW - 1], p21 = c[TW], p22 = c[TW + 1];
-                gx = (short)(((p02 + p22) * 3 + p12 * 10) - ((p00 + p20) * 3 + p10 * 10));
-                gy = (short)(((p20 - p00) + (p22 - p02)) * 3 + (p21 - p01) * 10);
+                const bool in = X >= 0 && X < I.w && Y >= 0 && Y < I.h;             // the derivative image is zero outside the level
+                gxs[k] = in ? (short)(((p02 + p22) * 3 + p12 * 10) - ((p00 + p20) * 3 + p10 * 10)) : (short)0;
+                gys[k] = in ? (short)(((p20 - p00) + (p22 - p02)) * 3 + (p21 - p01) * 10) : (short)0;
             }
-            sD[2 * t] = gx; sD[2 * t + 1] = gy;
+#pragma unroll
+            for (int k = 0; k < ND; k++) { const int t = l + 64 * k; if (t < DW * DW) { sD[2 * t] = gxs[k]; sD[2 * t + 1] = gys[k]; } }
         }
         __syncthreads();
         float aa = prevx - ipx, bb = prevy - ipy;
@@ -226,20 +287,16 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
         long long sA11 = 0, sA12 = 0, sA22 = 0;
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
-            const int p = l + 64 * j;
-            Iw[j] = 0; Ix[j] = 0; Iy[j] = 0;
-            if (p < win * win) {
-                const int y = p / win, x = p - y * win;
-                const uint8_t* s = &sI[(y + 1) * TW + (x + 1)];
-                const int ival = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[TW] * iw10 + s[TW + 1] * iw11, W_BITS - 5);
-                const short* d = &sD[2 * (y * DW + x)];
-                const int ixval = LVI_DESCALE(d[0] * iw00 + d[2] * iw01 + d[2 * DW] * iw10 + d[2 * DW + 2] * iw11, W_BITS);
-                const int iyval = LVI_DESCALE(d[1] * iw00 + d[3] * iw01 + d[2 * DW + 1] * iw10 + d[2 * DW + 3] * iw11, W_BITS);
-                Iw[j] = (short)ival; Ix[j] = (short)ixval; Iy[j] = (short)iyval;
-                sA11 += ixval * ixval; sA12 += ixval * iyval; sA22 += iyval * iyval;
-            }
+            const int y = wy[j], x = wx[j];
+            const uint8_t* s = &sI[(y + 1) * TW + (x + 1)];
+            const short* d = &sD[2 * (y * DW + x)];
+            const int ival = wv[j] ? LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[TW] * iw10 + s[TW + 1] * iw11, W_BITS - 5) : 0;
+            const int ixval = wv[j] ? LVI_DESCALE(d[0] * iw00 + d[2] * iw01 + d[2 * DW] * iw10 + d[2 * DW + 2] * iw11, W_BITS) : 0;
+            const int iyval = wv[j] ? LVI_DESCALE(d[1] * iw00 + d[3] * iw01 + d[2 * DW + 1] * iw10 + d[2 * DW + 3] * iw11, W_BITS) : 0;
+            Iw[j] = (short)ival; Ix[j] = (short)ixval; Iy[j] = (short)iyval;
+            sA11 += ixval * ixval; sA12 += ixval * iyval; sA22 += iyval * iyval;
         }
-        sA11 = wave_sum(sA11); sA12 = wave_sum(sA12); sA22 = wave_sum(sA22);
+        sA11 = wave_sum_i64(sA11); sA12 = wave_sum_i64(sA12); sA22 = wave_sum_i64(sA22);
         const float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
@@ -256,12 +313,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
                 if (level == 0) st = false;
                 break;
             }
-            __syncthreads();
-            for (int t = l; t < DW * DW; t += 64) {
-                const int ty = t / DW, tx = t - ty * DW;
-                sJ[t] = J.px[(size_t)reflect101(iny + ty, J.h) * J.w + reflect101(inx + tx, J.w)];
-            }
-            __syncthreads();
+            const int jo = target_window(inx, iny);
             aa = nextx - inx; bb = nexty - iny;
             iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
             iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
@@ -270,15 +322,11 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
             long long ib1 = 0, ib2 = 0;
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
-                const int p = l + 64 * q;
-                if (p < win * win) {
-                    const int y = p / win, x = p - y * win;
-                    const uint8_t* s = &sJ[y * DW + x];
-                    const int diff = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[DW] * iw10 + s[DW + 1] * iw11, W_BITS - 5) - Iw[q];
-                    ib1 += diff * Ix[q]; ib2 += diff * Iy[q];
-                }
+                const uint8_t* s = &sJ[jo + wy[q] * JW + wx[q]];          // a lane beyond the window reads pixel (0, 0): its Ix = Iy = 0
+                const int diff = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[JW] * iw10 + s[JW + 1] * iw11, W_BITS - 5) - Iw[q];
+                ib1 += diff * Ix[q]; ib2 += diff * Iy[q];
             }
-            ib1 = wave_sum(ib1); ib2 = wave_sum(ib2);
+            ib1 = wave_sum_i64(ib1); ib2 = wave_sum_i64(ib2);
             const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
             const float dx = (float)((A12 * b2 - A22 * b1) * D);
             const float dy = (float)((A12 * b1 - A11 * b2) * D);
@@ -295,12 +343,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
             const float nx = outx - halfWin, ny = outy - halfWin;
             const int inx = cv_floor(nx), iny = cv_floor(ny);
             if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) { st = false; continue; }
-            __syncthreads();
-            for (int t = l; t < DW * DW; t += 64) {
-                const int ty = t / DW, tx = t - ty * DW;
-                sJ[t] = J.px[(size_t)reflect101(iny + ty, J.h) * J.w + reflect101(inx + tx, J.w)];
-            }
-            __syncthreads();
+            const int jo = target_window(inx, iny);
             aa = nx - inx; bb = ny - iny;
             iw00 = cv_round((1.f - aa) * (1.f - bb) * (1 << W_BITS));
             iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
@@ -309,13 +352,9 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
             int esum = 0;                                  // |diff| are integers; the f32 sum of OpenCV is exact (< 2^24)
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
-                const int p = l + 64 * q;
-                if (p < win * win) {
-                    const int y = p / win, x = p - y * win;
-                    const uint8_t* s = &sJ[y * DW + x];
-                    const int diff = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[DW] * iw10 + s[DW + 1] * iw11, W_BITS - 5) - Iw[q];
-                    esum += abs(diff);
-                }
+                const uint8_t* s = &sJ[jo + wy[q] * JW + wx[q]];
+                const int diff = LVI_DESCALE(s[0] * iw00 + s[1] * iw01 + s[JW] * iw10 + s[JW + 1] * iw11, W_BITS - 5) - Iw[q];
+                esum += wv[q] ? abs(diff) : 0;
             }
             esum = wave_sum(esum);
             errv = (float)esum * 1.f / (32 * win * win);

@@ -4,6 +4,8 @@
     python tools/summarize_prof.py kernel <dir> <out.md>            # per-kernel time table from *_kernel_trace.csv
     python tools/summarize_prof.py steady <dir> <out.md> <nsteps>   # the same over the last nsteps bench steps only
     python tools/summarize_prof.py pmc <fetch_dir> <write_dir> <out.json>   # HBM bytes per launch per kernel
+    python tools/summarize_prof.py share <dir> <out.md> <nsteps>    # machine time per kernel with streams overlapping: every
+                                                                    #   instant is split evenly between the kernels resident then
 """
 import csv
 import glob
@@ -41,6 +43,49 @@ def kernel(d, out):
         fo.write("| kernel | calls | total us | avg us | min us | max us | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
         for k, (n, t, mn, mx) in rows:
             fo.write(f"| {k} | {n} | {t:.1f} | {t / n:.2f} | {mn:.2f} | {mx:.2f} | {100 * t / total:.1f} |\n")
+    print(open(out).read())
+
+
+def share(d, out, nsteps):
+    """who holds the machine when several streams overlap: over the last nsteps periods, every instant is divided evenly
+    between the kernels resident at that instant; also the distribution of the number of resident kernels."""
+    rows = []
+    for f in find(d, "*kernel_trace.csv"):
+        rows += list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ends = [i for i, r in enumerate(rows) if "org_count_kernel" in r["Kernel_Name"]]
+    if len(ends) < nsteps + 1:
+        raise SystemExit("not enough steps in the trace")
+    seg = rows[ends[-nsteps - 1]: ends[-1]]
+    t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["Start_Timestamp"])
+    ev = []
+    for r in rows:
+        a, b = max(int(r["Start_Timestamp"]), t0), min(int(r["End_Timestamp"]), t1)
+        if a < b:
+            k = f'{short(r["Kernel_Name"])} [grid {r["Grid_Size_X"]}x{r["Grid_Size_Y"]}x{r["Grid_Size_Z"]}]' if "Grid_Size_X" in r else short(r["Kernel_Name"])
+            ev.append((a, 1, k)); ev.append((b, -1, k))
+    ev.sort(key=lambda e: (e[0], e[1]))
+    live = defaultdict(int)
+    acc = defaultdict(float)
+    conc = defaultdict(float)
+    prev = t0
+    for t, d_, k in ev:
+        n = sum(live.values())
+        if t > prev:
+            conc[n] += t - prev
+            if n:
+                for kk, c in live.items():
+                    if c:
+                        acc[kk] += (t - prev) * c / n
+        prev = t
+        live[k] += d_
+    tot = (t1 - t0) / 1e3
+    with open(out, "w") as fo:
+        fo.write(f"last {nsteps} periods, {tot:.1f} us of wall time = {tot / nsteps:.1f} us per period; resident kernels: " +
+                 ", ".join(f"{n}: {100 * v / (t1 - t0):.1f} %" for n, v in sorted(conc.items())) + "\n\n")
+        fo.write("| kernel [launch geometry] | share of the wall time, us per period | % |\n|---|---:|---:|\n")
+        for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:40]:
+            fo.write(f"| {k} | {v / 1e3 / nsteps:.1f} | {100 * v / (t1 - t0):.1f} |\n")
     print(open(out).read())
 
 
@@ -115,5 +160,7 @@ if __name__ == "__main__":
         kernel(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "steady":
         steady(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    elif sys.argv[1] == "share":
+        share(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 3)
