@@ -523,11 +523,16 @@ struct PickArgs {
     float* out_xy; int* out_n; int* ncand;
 };
 
-// sequential minimum-distance selection (featureselect.cpp), one wavefront, ballot-resolved
+// sequential minimum-distance selection (featureselect.cpp), one wavefront, ballot-resolved.  A candidate is compared with
+// the accepted corners of the 3 x 3 grid cells around it (cell = min_dist, as OpenCV's own grid): the cells keep up to four
+// accepted indices each in LDS (corners at least min_dist apart: two fit a cell), so a candidate reads a handful of entries
+// instead of walking all accepted corners; a fifth corner in one cell, or a grid beyond the LDS budget, falls back to that walk.
 __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
 {
-    constexpr int ACC_MAX = 4096;
+    constexpr int ACC_MAX = 4096, GRID_MAX = 8192, CELL_CAP = 4;
     __shared__ short ax[ACC_MAX], ay[ACC_MAX], acx[ACC_MAX], acy[ACC_MAX];      // accepted corners and their grid cells (no division in the inner loop)
+    __shared__ unsigned char gcnt[GRID_MAX];
+    __shared__ unsigned short gent[GRID_MAX * CELL_CAP];
     const unsigned* vals = rs_result_in_B(a.d_nbits[0]) ? a.valsB : a.valsA;
     const int total = *a.total;
     const int l = threadIdx.x;
@@ -535,28 +540,57 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
     const bool filter = a.min_dist >= 1.0;
     const int cell = filter ? (int)rint(a.min_dist) : 1;
     const double md2 = a.min_dist * a.min_dist;
+    const int gw = (a.w + cell - 1) / cell, gh = (a.h + cell - 1) / cell;
+    bool grid = filter && gw * gh <= GRID_MAX;
+    if (grid) for (int c = l; c < gw * gh; c += 64) gcnt[c] = 0;
+    __syncthreads();
     int nacc = 0;
     // one corner past the capacity is enough to know the result does not fit (it is counted, not stored)
     const int limit = (a.max_corners > 0) ? min(a.max_corners, a.cap + 1) : a.cap + 1;
     bool overflow = false;
+    unsigned pnext = l < total ? vals[l] : 0u;             // the next batch's candidates are in flight while this one is resolved
     for (int base = 0; base < total && nacc < limit; base += 64) {
         const int i = base + l;
         bool alive = i < total;
         int x = 0, y = 0;
-        if (alive) { const int p = (int)vals[i]; y = p / a.w; x = p - y * a.w; }
+        const int p = (int)pnext;
+        pnext = i + 64 < total ? vals[i + 64] : 0u;
+        if (alive) { y = p / a.w; x = p - y * a.w; }
         const int xc = x / cell, yc = y / cell;
         if (alive && filter) {
-            for (int k = 0; k < nacc; k++) {
-                const int dxc = acx[k] - xc, dyc = acy[k] - yc;
-                if (dxc < -1 || dxc > 1 || dyc < -1 || dyc > 1) continue;
-                const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
-                if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
+            if (grid) {
+                for (int dyc = -1; dyc <= 1 && alive; dyc++) {
+                    const int cy = yc + dyc;
+                    if (cy < 0 || cy >= gh) continue;
+                    for (int dxc = -1; dxc <= 1 && alive; dxc++) {
+                        const int cx = xc + dxc;
+                        if (cx < 0 || cx >= gw) continue;
+                        const int c = cy * gw + cx, n = gcnt[c];
+                        for (int e = 0; e < n; e++) {
+                            const int k = gent[c * CELL_CAP + e];
+                            const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
+                            if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
+                        }
+                    }
+                }
+            } else {
+                for (int k = 0; k < nacc; k++) {
+                    const int dxc = acx[k] - xc, dyc = acy[k] - yc;
+                    if (dxc < -1 || dxc > 1 || dyc < -1 || dyc > 1) continue;
+                    const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
+                    if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
+                }
             }
         }
         uint64_t m = __ballot(alive);
         while (m && nacc < limit) {
             const int first = __ffsll((long long)m) - 1;
             const int fx = __shfl(x, first, 64), fy = __shfl(y, first, 64), fxc = __shfl(xc, first, 64), fyc = __shfl(yc, first, 64);
+            if (grid) {                                     // same for every lane: the cell of the accepted corner takes its index
+                const int c = fyc * gw + fxc, n = gcnt[c];
+                if (n < CELL_CAP && nacc < ACC_MAX) { if (l == first) { gent[c * CELL_CAP + n] = (unsigned short)nacc; gcnt[c] = (unsigned char)(n + 1); } }
+                else grid = false;                          // from here on: the walk over all accepted corners
+            }
             if (l == first) {
                 if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; acx[nacc] = (short)xc; acy[nacc] = (short)yc; }
                 if (nacc < a.cap) { a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y; }
