@@ -474,6 +474,7 @@ struct IcpArgs {
     float4* nn_ref;                               // [Q] where the feature stood at its last search (xyz) and a lower bound (w, squared) on the distance from there
                                                   // to every map point outside its five; nullptr: search in every iteration
     float knn_slack;                              // metres added to the radius of a bounded search (room for later iterations to skip theirs)
+    int xcd_map;                                  // residual workgroups are dealt to the XCDs in contiguous feature ranges (LVI_ICP_NO_XCD_MAP=1: in launch order)
 };
 
 __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
@@ -580,8 +581,14 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
     const IcpArgs& a = B_.a[blockIdx.z];
     if (a.st->done) return;
     const int nC = a.nq[0], nS = a.nq[1];
-    if (blockIdx.x * ICP_QPB >= nC + nS) return;
-    const bool stamp = (blockIdx.x == (nC + nS) / ICP_QPB / 2 && threadIdx.x == 0);     // a surf workgroup in the middle
+    // XCD-aware placement (speed only): workgroups b and b + 8 share an XCD and its L2, so XCD k takes a CONTIGUOUS eighth of the
+    // features — they come in voxel order, a spatial slab — and its L2 fetches that slab's part of the index and the map instead
+    // of all of it (every launch starts on cold L2s: the counters showed each of the eight L2s re-fetching the whole index)
+    const int nb = (nC + nS + ICP_QPB - 1) / ICP_QPB;
+    const int per_xcd = (nb + 7) / 8;
+    const int wg = a.xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if ((a.xcd_map && (int)(blockIdx.x >> 3) >= per_xcd) || wg >= nb) return;
+    const bool stamp = (wg == (nC + nS) / ICP_QPB / 2 && threadIdx.x == 0);     // a surf workgroup in the middle
     long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     __shared__ float sA[12], sT[6];
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
     // order is recomputed here with the search's own expression: the same Knn5, bit for bit, without a search.
     if (threadIdx.x < ICP_QPB) {
         const int ql = threadIdx.x;
-        const int t = blockIdx.x * ICP_QPB + ql;
+        const int t = wg * ICP_QPB + ql;
         const bool active = t < nC + nS;
         bool need = active;
         float r2 = KNN_R2_FULL;
@@ -659,7 +666,7 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
         float r2 = KNN_R2_FULL;
         if (gi < snsearch) {
             const int ql = slist[gi];
-            const int t = blockIdx.x * ICP_QPB + ql;
+            const int t = wg * ICP_QPB + ql;
             const bool isC = t < nC;
             const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
             const lvi_pt sel = to_map(sA, ori);
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
     __syncthreads();
     if (threadIdx.x < ICP_QPB) {
         const int ql = threadIdx.x;
-        const int t = blockIdx.x * ICP_QPB + ql;
+        const int t = wg * ICP_QPB + ql;
         double* row = srow[ql];
         bool ok = false;
         if (t < nC + nS) {
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
         double v = 0.0;
 #pragma unroll 8
         for (int q = 0; q < ICP_QPB; q++) v += srow[q][threadIdx.x];
-        a.partial[(size_t)blockIdx.x * 28 + threadIdx.x] = v;
+        a.partial[(size_t)wg * 28 + threadIdx.x] = v;
     }
     LVI_STAMP(4);
     if (stamp) { cyc[5] = clock64() - t_first; for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q]; }
@@ -1084,6 +1091,7 @@ IcpArgs icp_args(LidarDev& d)
     a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
     a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles; a.d_status = d.d_status; a.nn_prev = d.knn_bound ? d.nnPrev : nullptr;
     a.nn_ref = (d.knn_bound && d.knn_skip) ? d.nnRef : nullptr; a.knn_slack = d.knn_slack;
+    { static const bool no_map = getenv("LVI_ICP_NO_XCD_MAP") != nullptr; a.xcd_map = no_map ? 0 : 1; }
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;
@@ -1339,7 +1347,7 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
         // iteration 0 searches the unit ball with 8 lanes per feature; later iterations search the (much smaller) ball of the
         // previous neighbours, where the per-lane fixed cost dominates: fewer lanes per feature (d.icp_g1)
         const int G1 = it == 0 ? d.icp_g0 : d.icp_g1;
-        const dim3 rg(d.nblk_icp, 1, S);
+        const dim3 rg((d.nblk_icp + 7) & ~7, 1, S);               // a multiple of 8: the kernel deals its workgroups to the XCDs in contiguous ranges
         if (G1 == 8) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<8, 8>), rg, dim3(512), 0, cx.stream, B));
         else if (G1 == 4) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<4, 4>), rg, dim3(256), 0, cx.stream, B));
         else if (G1 == 2) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<2, 4>), rg, dim3(128), 0, cx.stream, B));
