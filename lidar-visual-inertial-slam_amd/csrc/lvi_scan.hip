@@ -333,11 +333,12 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
     __shared__ uint8_t s_pick[FEAT_SEG_CAP + 16], s_reach[FEAT_SEG_CAP + 16];
     __shared__ int8_t s_label[FEAT_SEG_CAP + 16];
     __shared__ uint64_t s_brk[FEAT_SEG_CAP / 64 + 2];         // bit j: column jump (or cloud edge) between j-1 and j
-    __shared__ unsigned short s_U[FEAT_THREADS + 4], s_L[FEAT_THREADS + 4];   // undecided / labelled bitmaps, one halfword per thread chunk (+1 pad in front)
+    __shared__ unsigned s_UL[FEAT_THREADS + 4];               // per thread chunk of 16 points: undecided bits (low half) and labelled bits (high half) in ONE word,
+                                                              // so that a neighbour reads a consistent pair (+1 pad in front)
     __shared__ unsigned short s_cand[FEAT_SEG_CAP];           // corner candidates (local indices); their order key is (curvature bits, index)
     __shared__ unsigned short s_sorted[FEAT_SEG_CAP];         // candidates by descending key
     __shared__ int s_ws[FEAT_THREADS / 64 + 2];
-    __shared__ int s_any, s_timeout;
+    __shared__ int s_anyr[3], s_timeout;
 
     // One workgroup per (ring, sector) when every sector of the ring is a regular one; the six workgroups of a ring
     // form a pipeline: loading, neighbour reach, candidate compaction and ranking of sector s+1 run while sector s is
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
     long long t_prev = stamp ? clock64() : 0, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
 
-    if (tid < 4) { s_U[tid == 0 ? 0 : FEAT_THREADS + tid] = 0; s_L[tid == 0 ? 0 : FEAT_THREADS + tid] = 0; }
+    if (tid < 4) s_UL[tid == 0 ? 0 : FEAT_THREADS + tid] = 0;
     if (tid == 0) { s_brk[FEAT_SEG_CAP / 64] = ~0ull, s_brk[FEAT_SEG_CAP / 64 + 1] = ~0ull; s_timeout = 0; }
     for (int j = FEAT_SEG_CAP + tid; j < FEAT_SEG_CAP + 32; j += FEAT_THREADS) s_curv[j] = 0.f;
     __syncthreads();
@@ -546,14 +547,21 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
             if (jhi >= jlo && v_pick[jhi] == 0 && s_curv[jhi] > a.edgeThreshold) take(jhi);
             for (int base = 0; base < ncand && taken < CORNERS_PER_SECTOR; base += 64) {
                 const int j = (base + l < ncand) ? (int)s_sorted[base + l] : -1;
-                bool alive = j >= 0 && v_pick[j] == 0;
+                const int rcj = j >= 0 ? (int)s_reach[j] : 0;              // every lane brings its candidate's reach: the walk below reads no LDS
+                bool alive = j >= 0 && s_pick[j] == 0;
                 uint64_t m = __ballot(alive);
                 while (m && taken < CORNERS_PER_SECTOR) {
                     const int first = __ffsll((long long)m) - 1;
-                    const int win = __shfl(j, first, 64);
-                    take(win);
+                    const int win = __builtin_amdgcn_readlane(j, first);          // `first` is wave-uniform: a scalar read, no LDS round trip
+                    const int rc = __builtin_amdgcn_readlane(rcj, first);
+                    // one store per lane 0..10 (the point and its +-5 neighbours within reach); this section runs on ONE wavefront,
+                    // whose LDS operations complete in order, so the plain s_pick is enough (no wait behind every volatile access)
+                    const int tgt = l <= 5 ? win + l : win - (l - 5);
+                    const bool wr = l <= 5 ? l <= (rc & 15) : (l <= 10 && l - 5 <= (rc >> 4));
+                    if (wr) s_pick[tgt] = 1;
+                    if (l == 0) { out_idx[taken] = k0 + win; s_label[win] = 1; }
+                    taken++;
                     // a taken point kills exactly the candidates within its reach
-                    const int rc = s_reach[win];
                     const int dj = j - win;
                     if (dj == 0 || (dj > 0 && dj <= (rc & 15)) || (dj < 0 && -dj <= (rc >> 4))) alive = false;
                     m = __ballot(alive);
@@ -583,38 +591,54 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
         {
 #pragma unroll
             for (int i = 0; i < FEAT_EPT; i++) if (((statc >> i) & 1u) && s_pick[jb + i] == 0) myU |= 1u << i;      // candidates the corner walk left unpicked
-            s_U[tid + 1] = (unsigned short)myU; s_L[tid + 1] = 0;
+            s_UL[tid + 1] = myU;
+        }
+        // the patterns transposed: em[d + 5] bit i <-> "the neighbour at offset d of point jb + i is reachable and earlier in the walk"
+        unsigned em[11];
+#pragma unroll
+        for (int d = 0; d < 11; d++) {
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < FEAT_EPT; i++) m |= (((unsigned)pat[i] >> d) & 1u) << i;
+            em[d] = m;
         }
         __syncthreads();
         LVI_STAMP(4);
         int rounds = 0;
+        // one barrier per round: three flags in rotation (a round raises flag it % 3, reads it after the barrier, and clears the
+        // flag of round it + 2, which nobody touches before the next barrier)
+        if (tid < 3) s_anyr[tid] = 0;
+        __syncthreads();
         for (int it = 0; it < FEAT_SEG_CAP; it++) {
-            if (tid == 0) s_any = 0;
-            __syncthreads();
             if (myU) {
-                // 48-bit windows: bit 16 + i <-> point jb + i
-                uint64_t Uw = (uint64_t)s_U[tid] | ((uint64_t)myU << 16) | ((uint64_t)s_U[tid + 2] << 32);
-                uint64_t Lw = (uint64_t)s_L[tid] | ((uint64_t)myL << 16) | ((uint64_t)s_L[tid + 2] << 32);
+                // 48-bit windows: bit 16 + i <-> point jb + i.  All 16 points of the chunk are resolved together, offset by offset
+                // (a point is decided once no earlier reachable neighbour is undecided; labelled iff none of them is labelled);
+                // three passes per round let a decision travel inside the chunk before the neighbours see it
+                const unsigned wp = s_UL[tid], wn = s_UL[tid + 2];
 #pragma unroll
-                for (int i = 0; i < FEAT_EPT; i++) {
-                    if (!(myU & (1u << i))) continue;
-                    const unsigned p = pat[i];
-                    const bool blocked = ((unsigned)(Lw >> (11 + i)) & p) != 0;
-                    const bool wait = ((unsigned)(Uw >> (11 + i)) & p) != 0;
-                    if (blocked || !wait) {
-                        myU &= ~(1u << i); Uw &= ~(1ull << (16 + i));
-                        if (!blocked) { myL |= 1u << i; Lw |= 1ull << (16 + i); }
+                for (int rep = 0; rep < 3; rep++) {
+                    const uint64_t Uw = (uint64_t)(wp & 0xFFFFu) | ((uint64_t)myU << 16) | ((uint64_t)(wn & 0xFFFFu) << 32);
+                    const uint64_t Lw = (uint64_t)(wp >> 16) | ((uint64_t)myL << 16) | ((uint64_t)(wn >> 16) << 32);
+                    unsigned blocked = 0, wait = 0;
+#pragma unroll
+                    for (int d = 0; d < 11; d++) {
+                        if (d == 5) continue;
+                        blocked |= em[d] & (unsigned)(Lw >> (11 + d));
+                        wait |= em[d] & (unsigned)(Uw >> (11 + d));
                     }
+                    myL |= myU & ~blocked & ~wait;
+                    myU &= ~(blocked | ~wait);
                 }
-                s_U[tid + 1] = (unsigned short)myU; s_L[tid + 1] = (unsigned short)myL;
-                if (myU) s_any = 1;
+                s_UL[tid + 1] = myU | (myL << 16);
+                if (myU) s_anyr[it % 3] = 1;
             }
             __syncthreads();
-            const int any = s_any;
+            const int any = s_anyr[it % 3];
+            if (tid == 0) s_anyr[(it + 2) % 3] = 0;
             rounds++;
-            __syncthreads();
             if (!any) break;
         }
+        __syncthreads();
         if (stamp) cyc[6] += rounds;
         LVI_STAMP(5);
         // ---- apply labels and their +-5 marks

@@ -585,7 +585,8 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
         uint64_t m = __ballot(alive);
         while (m && nacc < limit) {
             const int first = __ffsll((long long)m) - 1;
-            const int fx = __shfl(x, first, 64), fy = __shfl(y, first, 64), fxc = __shfl(xc, first, 64), fyc = __shfl(yc, first, 64);
+            const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);      // `first` is wave-uniform: scalar reads
+            const int fxc = __builtin_amdgcn_readlane(xc, first), fyc = __builtin_amdgcn_readlane(yc, first);
             if (grid) {                                     // same for every lane: the cell of the accepted corner takes its index
                 const int c = fyc * gw + fxc, n = gcnt[c];
                 if (n < CELL_CAP && nacc < ACC_MAX) { if (l == first) { gent[c * CELL_CAP + n] = (unsigned short)nacc; gcnt[c] = (unsigned char)(n + 1); } }
