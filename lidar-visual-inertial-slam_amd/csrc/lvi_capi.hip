@@ -317,6 +317,8 @@ int32_t lvi_scan_upload_device(lvi_lidar* h, const void* d_pts, int32_t n_raw)
 // every slot of h reads the raw local map at (c, s): the handle's own memory, or another handle's (lvi_map_share)
 static void bind_raw_map(lvi_lidar* h, lvi_pt* c, lvi_pt* s)
 {
+    // a captured launch sequence froze the old pointers (lvi_scan_replay_enqueue): it is recaptured on the next call
+    if (h->d.graphExec) { (void)hipGraphExecDestroy(h->d.graphExec); h->d.graphExec = nullptr; }
     for (LidarDev* q : h->slots) {
         q->mapCornerRaw = c; q->mapSurfRaw = s;
         const VoxSegStatic st[2] = {VoxSegStatic{c, nullptr, q->mapCornerDS, q->P.mappingCornerLeafSize}, VoxSegStatic{s, nullptr, q->mapSurfDS, q->P.mappingSurfLeafSize}};

@@ -939,6 +939,25 @@ def test_map_share_reads_the_owner_map_in_place(pkg, hip, scene):
     for z in range(2):
         np.testing.assert_array_equal(bits(recs[z, :6]), ref[0])
     bb.close()
+    # a launch sequence captured against b's OWN map (same sizes) must not survive the switch to the shared one
+    c = pkg.LidarHotpath(hip, **small_params(icp_max_iters=6, icp_disable_break=1))
+    shifted_c, shifted_s = scene["map_corner"].copy(), scene["map_surf"].copy()
+    shifted_c["x"] += 0.5; shifted_s["x"] += 0.5
+    c.map_set(shifted_c, shifted_s)
+    import torch
+    d_scan = torch.from_numpy(scan.view(np.uint8).copy()).to("cuda")
+    d_rec = torch.zeros(8, dtype=torch.float32, device="cuda")
+    c.scan_replay_enqueue(d_scan.data_ptr(), len(scan), guess, d_rec.data_ptr(), True); c.sync()
+    own = d_rec.cpu().numpy().copy()
+    o6 = pkg.LidarHotpath(hip, **small_params(icp_max_iters=6, icp_disable_break=1))
+    o6.map_set(scene["map_corner"], scene["map_surf"])
+    o6.scan_replay_enqueue(d_scan.data_ptr(), len(scan), guess, d_rec.data_ptr(), True); o6.sync()
+    want = d_rec.cpu().numpy().copy()
+    assert not np.array_equal(bits(own[:6]), bits(want[:6]))
+    c.map_share(o6)
+    c.scan_replay_enqueue(d_scan.data_ptr(), len(scan), guess, d_rec.data_ptr(), True); c.sync()
+    np.testing.assert_array_equal(bits(d_rec.cpu().numpy()[:6]), bits(want[:6]))
+    c.close(); o6.close()
     # b uploads a different map of its own: the owner still matches against the first one
     half_c, half_s = scene["map_corner"][: len(scene["map_corner"]) // 2], scene["map_surf"][: len(scene["map_surf"]) // 2]
     b.map_set(half_c, half_s)
