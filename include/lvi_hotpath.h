@@ -259,9 +259,10 @@ int32_t lvi_map_upload_device(lvi_lidar *h, const void *d_corner_raw, int32_t nc
 /* [hip only] h reads the raw local map `owner` holds, in place: several handles of one GPU that match scans against the
  * same local map (replay harnesses: laserCloud{Corner,Surf}FromMap is one read-only cloud, mapOptimization.cpp:958-965)
  * keep ONE copy of it in HBM, which then also stays in the 256 MB memory-side cache while every handle re-voxelises it.
- * Each handle still builds its own downsampled map and index.  `owner` must hold a map, live on the same GPU, and must
- * neither change its map nor be destroyed while h shares it; a later lvi_map_upload* / lvi_map_assemble on h ends the
- * sharing (h goes back to its own memory).  The oracle copies the clouds instead (same results). */
+ * Each handle still builds its own downsampled map and index.  `owner` must hold a map and live on the same GPU; while h shares
+ * it, lvi_map_upload* / lvi_map_assemble on `owner` fail with LVI_ERR_STATE and `owner` must not be destroyed (destroy the
+ * sharing handles first).  A later lvi_map_upload* / lvi_map_assemble on h, or its destruction, ends the sharing (h goes back
+ * to its own memory).  The oracle copies the clouds instead (same results, no such restriction). */
 int32_t lvi_map_share(lvi_lidar *h, lvi_lidar *owner);
 
 /* [hip only] the whole per-scan path in one call, for replay harnesses: scan (device pointer, Msg.point_num

@@ -60,6 +60,8 @@ struct lvi_lidar {
     LidarDev& cur() { return *slots[sel]; }
     std::vector<int32_t> vkeys, vcells, vcounts;    // debug of the last lvi_voxel_downsample
     bool have_icp_host = false;
+    lvi_lidar* share_owner = nullptr;               // lvi_map_share: the handle whose raw map this one reads
+    int shared_by = 0;                              // handles that read this one's raw map: it must not change while > 0
 };
 
 namespace {
@@ -239,6 +241,7 @@ void lvi_lidar_destroy(lvi_lidar* h)
     if (!h) return;
     LidarDev& d = h->d;
     (void)hipSetDevice(d.device);
+    if (h->share_owner) { h->share_owner->shared_by--; h->share_owner = nullptr; }      // (destroying an OWNER that is still shared is the caller's error)
     if (d.ctx.stream) { (void)hipStreamSynchronize(d.ctx.stream); }
     if (d.ctx2.stream) { (void)hipStreamSynchronize(d.ctx2.stream); }
     d.prof.collect();
@@ -329,6 +332,7 @@ static void bind_raw_map(lvi_lidar* h, lvi_pt* c, lvi_pt* s)
 static void unshare_map(lvi_lidar* h)
 {
     if (h->d.mapCornerRaw == h->d.mapCornerOwn) return;
+    if (h->share_owner) { h->share_owner->shared_by--; h->share_owner = nullptr; }
     join_map(h->d); sync(h->d);
     bind_raw_map(h, h->d.mapCornerOwn, h->d.mapSurfOwn);
     h->d.have_map_raw = false; h->d.n_map_corner = h->d.n_map_surf = 0; h->d.voxMap.bbox_cached = false;
@@ -345,6 +349,8 @@ int32_t lvi_map_share(lvi_lidar* h, lvi_lidar* owner)
     return guarded(h, [&]() -> int32_t {
         join_map(owner->d); sync(owner->d);                         // the owner's upload / assembly has landed
         join_map(h->d); sync(h->d);
+        if (h->share_owner) h->share_owner->shared_by--;
+        h->share_owner = owner; owner->shared_by++;
         bind_raw_map(h, owner->d.mapCornerRaw, owner->d.mapSurfRaw);
         LidarDev& d = h->d;
         d.n_map_corner = owner->d.n_map_corner; d.n_map_surf = owner->d.n_map_surf; d.have_map_raw = true; d.voxMap.bbox_cached = false;
@@ -358,6 +364,7 @@ int32_t lvi_map_upload_device(lvi_lidar* h, const void* c, int32_t nc, const voi
 {
     if (!h || nc < 0 || ns < 0 || (nc > 0 && !c) || (ns > 0 && !s)) return fail(LVI_ERR_INVALID_ARG, "bad map arguments");
     if (nc > h->d.map_cap || ns > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    if (h->shared_by > 0) return fail(LVI_ERR_STATE, "other handles read this handle's map (lvi_map_share)");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         unshare_map(h);
@@ -387,6 +394,7 @@ int32_t lvi_map_upload(lvi_lidar* h, const lvi_pt* c, int32_t nc, const lvi_pt* 
 {
     if (!h || nc < 0 || ns < 0 || (nc > 0 && !c) || (ns > 0 && !s)) return fail(LVI_ERR_INVALID_ARG, "bad map arguments");
     if (nc > h->d.map_cap || ns > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    if (h->shared_by > 0) return fail(LVI_ERR_STATE, "other handles read this handle's map (lvi_map_share)");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         unshare_map(h);
@@ -718,6 +726,7 @@ int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_key
         tc += h->d.kf_n_c[k]; ts += h->d.kf_n_s[k];
     }
     if (tc > h->d.map_cap || ts > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
+    if (h->shared_by > 0) return fail(LVI_ERR_STATE, "other handles read this handle's map (lvi_map_share)");
     return guarded(h, [&]() -> int32_t {
         unshare_map(h);
         stage_map_assemble(h->d, key_indices, n_keys);                                      // extractCloud's fuse loop into the raw map (slot 0)

@@ -958,6 +958,9 @@ def test_map_share_reads_the_owner_map_in_place(pkg, hip, scene):
     c.scan_replay_enqueue(d_scan.data_ptr(), len(scan), guess, d_rec.data_ptr(), True); c.sync()
     np.testing.assert_array_equal(bits(d_rec.cpu().numpy()[:6]), bits(want[:6]))
     c.close(); o6.close()
+    # the owner cannot change its map while it is shared
+    with pytest.raises(pkg.LviError):
+        owner.map_upload(scene["map_corner"], scene["map_surf"])
     # b uploads a different map of its own: the owner still matches against the first one
     half_c, half_s = scene["map_corner"][: len(scene["map_corner"]) // 2], scene["map_surf"][: len(scene["map_surf"]) // 2]
     b.map_set(half_c, half_s)
@@ -966,6 +969,7 @@ def test_map_share_reads_the_owner_map_in_place(pkg, hip, scene):
     again = match(owner)
     for x, y in zip(ref, again):
         np.testing.assert_array_equal(x, y)
+    owner.map_upload(scene["map_corner"], scene["map_surf"])          # nobody shares it any more
     b.close(); owner.close()
 
 
