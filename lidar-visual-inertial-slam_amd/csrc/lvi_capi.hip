@@ -1,3 +1,4 @@
+#include <atomic>
 // C-ABI of the lidar half (include/lvi_hotpath.h) over the HIP stages.  Host-side only:
 // argument checks, H2D/D2H, stage ordering, error mapping.  No CPU fallback exists: every
 // compute entry point enqueues HIP kernels or fails.
@@ -61,7 +62,7 @@ struct lvi_lidar {
     std::vector<int32_t> vkeys, vcells, vcounts;    // debug of the last lvi_voxel_downsample
     bool have_icp_host = false;
     lvi_lidar* share_owner = nullptr;               // lvi_map_share: the handle whose raw map this one reads
-    int shared_by = 0;                              // handles that read this one's raw map: it must not change while > 0
+    std::atomic<int> shared_by{0};                  // handles that read this one's raw map (they may live on other host threads): it must not change while > 0
 };
 
 namespace {
