@@ -210,7 +210,7 @@ constexpr float KNN_R2_FULL = 0x1.fffffep-1f;
 template <int G, int KNN_KB>
 __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
                                                   float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr, float r2max = KNN_R2_FULL,
-                                                  float* lb2 = nullptr)
+                                                  bool want_lb = false, float* lb2 = nullptr)
 {
     constexpr int KNN_RPL = (25 + G - 1) / G;         // rows per lane
 #define LVI_KT(slot) do { if (tk) tk[slot] = clock64(); } while (0)
@@ -288,7 +288,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 // sqDis < 1.0, and if five such neighbours exist they ARE the five nearest.
                 const bool take = f0 + u < T && dist <= r2max;
                 const unsigned long long key = take ? knn_key(dist, __float_as_int(p[u].intensity)) : KNN_EMPTY;
-                if (lb2) { const unsigned dr = (unsigned)((key < r.k[4] ? r.k[4] : key) >> 32); rej = dr < rej ? dr : rej; }
+                if (want_lb) { const unsigned dr = (unsigned)((key < r.k[4] ? r.k[4] : key) >> 32); rej = dr < rej ? dr : rej; }
                 knn_insert(r, key);
             }
         }
@@ -304,7 +304,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         out.d[k] = __uint_as_float((unsigned)(h >> 32)); out.i[k] = (int)(unsigned)h;
         if (r.k[0] == h && h != KNN_EMPTY) { r.k[0] = r.k[1]; r.k[1] = r.k[2]; r.k[2] = r.k[3]; r.k[3] = r.k[4]; r.k[4] = KNN_EMPTY; }
     }
-    if (lb2) {
+    if (want_lb) {
         // every map point outside the five is either a candidate that lost its place (in a lane's list or in the merge: the
         // smallest such distance is rej / a lane's remaining head), or was never taken: farther than sqrt(r2max)
         const unsigned hd = (unsigned)(r.k[0] >> 32);
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
             r2 = sr2[gi];
             Knn5 r;
             float lb2 = 0.f;
-            knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref ? &lb2 : nullptr);
+            knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
             if (sub == 0) {
                 snn[ql] = r;
                 if (a.nn_prev) {
