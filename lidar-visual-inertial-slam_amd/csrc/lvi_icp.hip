@@ -239,30 +239,37 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         const int inv_ny = ny == 1 ? 256 : (ny == 2 ? 128 : (ny == 3 ? 86 : (ny == 4 ? 64 : 52)));      // (rr * inv_ny) >> 8 == rr / ny for rr < 25
         int off[KNN_RPL], st[KNN_RPL + 1];
         st[0] = 0;
+        // rows a lane of this wavefront can own at most (uniform when the whole wavefront is here; a lane's own need is always
+        // covered, so a partly active wavefront is merely less tidy): slots beyond it issue no loads at all
+        int tcap = (nrows + G - 1) / G;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tcap = max(tcap, __shfl_xor(tcap, o, 64));
+#pragma unroll
+        for (int t = 0; t < KNN_RPL; t++) { off[t] = 0; st[t + 1] = 0; }
 #pragma unroll
         for (int t = 0; t < KNN_RPL; t++) {
-            const int rr = sub + G * t;
-            int rb = 0, len = 0;
-            const int rq = (rr * inv_ny) >> 8;
-            const int dy = y0 + rr - rq * ny, dz = z0 + rq;
-            const int y = cy + dy, z = cz + dz;
-            if (rr < nrows && y >= 0 && y < m.dim[1] && z >= 0 && z < m.dim[2]) {
+            if (t < tcap) {                                 // wave-uniform: a scalar branch, the loop stays unrolled
+                // no branch around the two bound loads: a row that does not count reads cells 0 and 1 and is masked afterwards, so that
+                // the loads of all the lane's rows are in flight together (inside nested branches every row waited for its own pair)
+                const int rr = sub + G * t;
+                const int rq = (rr * inv_ny) >> 8;
+                const int dy = y0 + rr - rq * ny, dz = z0 + rq;
+                const int y = cy + dy, z = cz + dz;
+                bool ok = rr < nrows && y >= 0 && y < m.dim[1] && z >= 0 && z < m.dim[2];
                 // distance (m) from the query to the row's slab along y and z; 0 inside
                 const float ddy = dy == 0 ? 0.f : (dy > 0 ? (float)dy - ty : ty - (float)(dy + 1)) * e;
                 const float ddz = dz == 0 ? 0.f : (dz > 0 ? (float)dz - tz : tz - (float)(dz + 1)) * e;
                 // margins: the f32 distance of a candidate may round below 1 when the exact one is just above
                 const float rem = r2max + 1e-4f - ddy * ddy - ddz * ddz;
-                if (rem > 0.f) {
-                    const float sx = sqrtf(rem) * inv_e + 1e-4f;
-                    const int x0 = max(cx + (int)floorf(tx - sx), 0), x1 = min(cx + (int)floorf(tx + sx), m.dim[0] - 1);
-                    if (x0 <= x1) {
-                        const int row = (z * m.dim[1] + y) * m.dim[0];
-                        rb = cell_start[row + x0];
-                        len = cell_start[row + x1 + 1] - rb;
-                    }
-                }
+                ok = ok && rem > 0.f;
+                const float sx = sqrtf(fmaxf(rem, 0.f)) * inv_e + 1e-4f;
+                const int x0 = max(cx + (int)floorf(tx - sx), 0), x1 = min(cx + (int)floorf(tx + sx), m.dim[0] - 1);
+                ok = ok && x0 <= x1;
+                const int row = ok ? (z * m.dim[1] + y) * m.dim[0] : 0;
+                const int rb = cell_start[row + (ok ? x0 : 0)];
+                const int re = cell_start[row + (ok ? x1 : 0) + 1];
+                off[t] = ok ? rb : 0; st[t + 1] = ok ? re - rb : 0;
             }
-            off[t] = rb; st[t + 1] = len;
         }
 #pragma unroll
         for (int t = 0; t < KNN_RPL; t++) { const int len = st[t + 1]; st[t + 1] = st[t] + len; off[t] -= st[t]; }
@@ -277,7 +284,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 int o = off[0];
 #pragma unroll
                 for (int t = 1; t < KNN_RPL; t++) o = f >= st[t] ? off[t] : o;
-                if (f < T) p[u] = sorted[f + o];
+                p[u] = sorted[f < T ? f + o : 0];               // unconditional (entry 0 when past the list: masked below): the batch's loads travel together
             }
             LVI_KT(2);
 #pragma unroll
@@ -579,8 +586,11 @@ template <int G, int KB>
 __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
 {
     const IcpArgs& a = B_.a[blockIdx.z];
-    if (a.st->done) return;
+    // everything the prologue needs is requested before the first value is tested (one round trip instead of four in a row)
+    const int done = a.st->done, iters_now = a.st->iters;
     const int nC = a.nq[0], nS = a.nq[1];
+    const float poseA = threadIdx.x < 12 ? a.st->pose.A[threadIdx.x] : 0.f, poseT = threadIdx.x < 6 ? a.st->pose.trig[threadIdx.x] : 0.f;
+    if (done) return;
     // XCD-aware placement (speed only): workgroups b and b + 8 share an XCD and its L2, so XCD k takes a CONTIGUOUS eighth of the
     // features — they come in voxel order, a spatial slab — and its L2 fetches that slab's part of the index and the map instead
     // of all of it (every launch starts on cold L2s: the counters showed each of the eight L2s re-fetching the whole index)
@@ -597,8 +607,8 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
     __shared__ float sr2[ICP_QPB];                  // search radius (squared) of the features that search, in list order
     __shared__ unsigned char slist[ICP_QPB];        // the features (workgroup-local) that search in this iteration
     __shared__ int snsearch;
-    if (threadIdx.x < 12) sA[threadIdx.x] = a.st->pose.A[threadIdx.x];
-    if (threadIdx.x < 6) sT[threadIdx.x] = a.st->pose.trig[threadIdx.x];
+    if (threadIdx.x < 12) sA[threadIdx.x] = poseA;
+    if (threadIdx.x < 6) sT[threadIdx.x] = poseT;
     __syncthreads();
     // Phase 0, first wavefront, one lane per feature.  From the second iteration on a feature knows its previous five
     // neighbours; their distances under the new pose bound the fifth-nearest distance (five map points lie inside that ball),
@@ -613,7 +623,7 @@ __global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
         const bool active = t < nC + nS;
         bool need = active;
         float r2 = KNN_R2_FULL;
-        if (active && a.nn_prev && a.st->iters > 0) {
+        if (active && a.nn_prev && iters_now > 0) {
             const bool isC = t < nC;
             const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
             const lvi_pt sel = to_map(sA, ori);
