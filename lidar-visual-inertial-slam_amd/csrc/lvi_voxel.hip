@@ -551,13 +551,18 @@ __global__ __launch_bounds__(256) void vb_scatter_det_kernel(Batch<VoxArgs> B_)
     lvi_pt* __restrict__ dst = a.bucketed + (size_t)s * a.seg_cap;
     constexpr int IT = VB_STILE / 256;
     for (int base = i0; base < i1; base += VB_STILE) {
-        lvi_pt p[IT]; int bin[IT]; unsigned rk[IT];
+        lvi_pt p[IT]; int bin[IT]; unsigned rk[IT]; bool keep[IT];
 #pragma unroll
         for (int u = 0; u < IT; u++) {
+            // unconditional loads (index clamped into the range, the lane masked afterwards): behind a per-element branch every
+            // load of the tile waited for the one before it
             const int i = base + u * 256 + threadIdx.x;
-            bin[u] = -1;
-            if (i < i1 && (!mask || mask[i])) { p[u] = in[i]; bin[u] = (int)(vox_key_of_pt(g, p[u]) >> sh); }
+            const int ic = min(i, i1 - 1);
+            keep[u] = i < i1 && (!mask || mask[ic]);
+            p[u] = in[ic];
         }
+#pragma unroll
+        for (int u = 0; u < IT; u++) bin[u] = keep[u] ? (int)(vox_key_of_pt(g, p[u]) >> sh) : -1;
 #pragma unroll
         for (int u = 0; u < IT; u++) {
             const WaveRun r = wave_runs((unsigned)bin[u]);
@@ -585,6 +590,9 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
     unsigned* cur = a.cursor + (size_t)s * VB_NB * VB_PAD;
     __shared__ int ws[8];
     constexpr int PER = VB_NB / 256;                    // consecutive bins per thread
+    // (one source pointer chosen up front: a per-element choice between two arrays serialised the 16 loads of a thread)
+    const unsigned* cnt_src = a.binCountCached ? a.binCountCached + (size_t)s * VB_NB : gc;
+    const size_t cnt_stride = a.binCountCached ? 1 : VB_PAD;
     int v[PER], sum = 0, csum = 0, msum = 0, lsum = 0;
     const bool wide = a.grid[s].bin_shift > VB_CL_LOG;
     // chunks of a bin: none for a light bin (<= VB_LIGHT points: one wavefront of vb_light_kernel takes it), else ceil(n / VB_CH)
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         const int b = threadIdx.x * PER + j;
-        v[j] = b < nbins ? (int)(a.binCountCached ? a.binCountCached[(size_t)s * VB_NB + b] : gc[(size_t)b * VB_PAD]) : 0;
+        v[j] = b < nbins ? (int)cnt_src[(size_t)min(b, VB_NB - 1) * cnt_stride] : 0;
         sum += v[j];
         const int nch = chunks_of(v[j]);
         csum += nch; msum += nch > 1 ? nch : 0;
@@ -636,13 +644,16 @@ __global__ __launch_bounds__(256) void vb_scatter_kernel(Batch<VoxArgs> B_)
     const lvi_pt* __restrict__ in = a.st[s].in + off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
     constexpr int IT = VB_STILE / 256;
-    lvi_pt p[IT]; int bin[IT]; unsigned rk[IT];
+    lvi_pt p[IT]; int bin[IT]; unsigned rk[IT]; bool keep[IT];
 #pragma unroll
-    for (int u = 0; u < IT; u++) {
+    for (int u = 0; u < IT; u++) {                      // unconditional loads, clamped index (base < n here), lanes masked afterwards
         const int i = base + u * 256 + threadIdx.x;
-        bin[u] = -1;
-        if (i < n && (!mask || mask[i])) { p[u] = in[i]; bin[u] = (int)(vox_key_of_pt(g, p[u]) >> sh); }
+        const int ic = min(i, n - 1);
+        keep[u] = i < n && (!mask || mask[ic]);
+        p[u] = in[ic];
     }
+#pragma unroll
+    for (int u = 0; u < IT; u++) bin[u] = keep[u] ? (int)(vox_key_of_pt(g, p[u]) >> sh) : -1;
 #pragma unroll
     for (int u = 0; u < IT; u++) {                      // rank inside (tile, bin): any order will do; one LDS atomic per run of lanes,
         const WaveRun r = wave_runs((unsigned)bin[u]);  // so that a run lands on consecutive addresses (measured: 56 vs 59 us)
