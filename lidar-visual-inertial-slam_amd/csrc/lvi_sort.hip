@@ -34,10 +34,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(SortArgs a, const i
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
+    unsigned kk[RS_ITEMS];                                  // unconditional loads (clamped index): all of a thread's keys in flight together
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) kk[i] = keys[min(base + i * RS_THREADS + (int)threadIdx.x, n - 1)];
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const int idx = base + i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+        if (idx < n) atomicAdd(&h[(kk[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
     a.hist[((size_t)s * 256 + threadIdx.x) * a.nblk + blockIdx.x] = h[threadIdx.x];
@@ -104,11 +107,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(SortArgs a, cons
     const int cbase = base + w * (RS_ITEMS * 64);
     const uint64_t lt = lanemask_lt();
 #pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {                    // unconditional loads (clamped index), all in flight before the ranking below
+        const int ic = min(cbase + i * 64 + l, n - 1);
+        k[i] = srcK[ic]; v[i] = srcV[ic];
+    }
+#pragma unroll
     for (int i = 0; i < RS_ITEMS; i++) {
         const int idx = cbase + i * 64 + l;
         const bool valid = idx < n;
-        k[i] = valid ? srcK[idx] : 0u;
-        v[i] = valid ? srcV[idx] : 0u;
+        if (!valid) { k[i] = 0u; v[i] = 0u; }
         const unsigned d = (k[i] >> shift) & 255u;
         uint64_t peers = __ballot(valid);
 #pragma unroll

@@ -461,10 +461,16 @@ __global__ __launch_bounds__(256) void vb_hist_kernel(Batch<VoxArgs> B_)
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
     // grid-stride over the tiles: one LDS histogram and one flush per workgroup, however many tiles it takes
     for (int base = blockIdx.x * VB_TILE; base < n; base += gridDim.x * VB_TILE) {
-#pragma unroll 4
-        for (int u = 0; u < VB_TILE / 256; u++) {
-            const int i = base + u * 256 + threadIdx.x;
-            if (i < n && (!mask || mask[i])) atomicAdd(&cnt[vox_key_of_pt(g, in[i]) >> sh], 1u);
+        for (int u0 = 0; u0 < VB_TILE / 256; u0 += 8) {                  // eight unconditional loads in flight (clamped index, masked lanes)
+            lvi_pt p[8]; bool keep[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = base + (u0 + u) * 256 + threadIdx.x, ic = min(i, n - 1);
+                keep[u] = i < n && (!mask || mask[ic]);
+                p[u] = in[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (keep[u]) atomicAdd(&cnt[vox_key_of_pt(g, p[u]) >> sh], 1u);
         }
     }
     __syncthreads();
@@ -498,10 +504,16 @@ __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
     const lvi_pt* __restrict__ in = a.st[s].in + off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
     for (int base = i0; base < i1; base += VB_STILE) {
-#pragma unroll 4
-        for (int u = 0; u < VB_STILE / 256; u++) {
-            const int i = base + u * 256 + threadIdx.x;
-            if (i < i1 && (!mask || mask[i])) atomicAdd(&cnt[vox_key_of_pt(g, in[i]) >> sh], 1u);
+        for (int u0 = 0; u0 < VB_STILE / 256; u0 += 8) {
+            lvi_pt p[8]; bool keep[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = base + (u0 + u) * 256 + threadIdx.x, ic = min(i, i1 - 1);
+                keep[u] = i < i1 && (!mask || mask[ic]);
+                p[u] = in[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (keep[u]) atomicAdd(&cnt[vox_key_of_pt(g, p[u]) >> sh], 1u);
         }
     }
     __syncthreads();
@@ -600,7 +612,8 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
 #pragma unroll
     for (int j = 0; j < PER; j++) {
         const int b = threadIdx.x * PER + j;
-        v[j] = b < nbins ? (int)cnt_src[(size_t)min(b, VB_NB - 1) * cnt_stride] : 0;
+        const int vj = (int)cnt_src[(size_t)min(b, VB_NB - 1) * cnt_stride];        // unconditional: all 16 loads of the thread in flight
+        v[j] = b < nbins ? vj : 0;
         sum += v[j];
         const int nch = chunks_of(v[j]);
         csum += nch; msum += nch > 1 ? nch : 0;
