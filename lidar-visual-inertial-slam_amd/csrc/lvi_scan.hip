@@ -828,9 +828,12 @@ __global__ void feat_finalize_kernel(Batch<FeatArgs> B_)
     const FeatArgs& a = B_.a[blockIdx.z];
     __shared__ int off[MAX_N_SCAN * 6 + 1];
     const int ns = a.N_SCAN * 6;
+    __shared__ int scnt[MAX_N_SCAN * 6];
+    for (int s = threadIdx.x; s < ns; s += blockDim.x) scnt[s] = a.sector_cnt[s];      // one round trip for all sectors (thread 0 alone: one per sector)
+    __syncthreads();
     if (threadIdx.x == 0) {
         int o = 0;
-        for (int s = 0; s < ns; s++) { off[s] = o; o += a.sector_cnt[s]; }
+        for (int s = 0; s < ns; s++) { off[s] = o; o += scnt[s]; }
         off[ns] = o;
         *a.d_ncorner = o;
         for (int r = 0; r < a.N_SCAN; r++) { a.ringDyn[r].in_off = a.ringBase[r]; a.ringDyn[r].n = a.ringBase[r + 1] - a.ringBase[r]; }
@@ -850,7 +853,7 @@ __global__ void feat_finalize_kernel(Batch<FeatArgs> B_)
     }
     for (int t = threadIdx.x; t < ns * CORNERS_PER_SECTOR; t += blockDim.x) {
         const int s = t / CORNERS_PER_SECTOR, q = t % CORNERS_PER_SECTOR;
-        if (q < a.sector_cnt[s]) {
+        if (q < scnt[s]) {
             const int k = a.sector_idx[s * CORNERS_PER_SECTOR + q];
             a.corner_idx[off[s] + q] = k;
             a.corner[off[s] + q] = a.pts[k];

@@ -185,14 +185,23 @@ __global__ __launch_bounds__(64) void vox_setup_kernel(Batch<VoxArgs> B_)
         float ilo = INFINITY, ihi = -INFINITY;
         int c = 0;
         const int nb_used = a.nblk_mm;
-        for (int b = threadIdx.x; b < nb_used; b += 64) {
-            const float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + b) * 12;
-            const int cb = __float_as_int(rec[6]);
-            if (cb > 0) {
-                c += cb;
+        for (int b0 = threadIdx.x; b0 < nb_used; b0 += 64 * 4) {              // four records per lane in flight (min / max / integer sum: any order)
+            float r[4][9];
 #pragma unroll
-                for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], rec[d]); hi[d] = fmaxf(hi[d], rec[3 + d]); }
-                ilo = fminf(ilo, rec[7]); ihi = fmaxf(ihi, rec[8]);
+            for (int u = 0; u < 4; u++) {
+                const float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + min(b0 + 64 * u, nb_used - 1)) * 12;
+#pragma unroll
+                for (int q = 0; q < 9; q++) r[u][q] = rec[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int cb = b0 + 64 * u < nb_used ? __float_as_int(r[u][6]) : 0;
+                if (cb > 0) {
+                    c += cb;
+#pragma unroll
+                    for (int d = 0; d < 3; d++) { lo[d] = fminf(lo[d], r[u][d]); hi[d] = fmaxf(hi[d], r[u][3 + d]); }
+                    ilo = fminf(ilo, r[u][7]); ihi = fmaxf(ihi, r[u][8]);
+                }
             }
         }
         c = wave_sum(c);
@@ -610,10 +619,11 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
     // chunks of a bin: none for a light bin (<= VB_LIGHT points: one wavefront of vb_light_kernel takes it), else ceil(n / VB_CH)
     auto chunks_of = [&](int n) { return wide ? (n > 0 ? 1 : 0) : (n <= VB_LIGHT ? 0 : (n + VB_CH - 1) / VB_CH); };
 #pragma unroll
+    for (int j = 0; j < PER; j++) v[j] = (int)cnt_src[(size_t)min((int)threadIdx.x * PER + j, VB_NB - 1) * cnt_stride];   // all 16 loads in flight
+#pragma unroll
     for (int j = 0; j < PER; j++) {
         const int b = threadIdx.x * PER + j;
-        const int vj = (int)cnt_src[(size_t)min(b, VB_NB - 1) * cnt_stride];        // unconditional: all 16 loads of the thread in flight
-        v[j] = b < nbins ? vj : 0;
+        v[j] = b < nbins ? v[j] : 0;
         sum += v[j];
         const int nch = chunks_of(v[j]);
         csum += nch; msum += nch > 1 ? nch : 0;
@@ -983,7 +993,9 @@ __global__ __launch_bounds__(256) void vb_outscan_kernel(Batch<VoxArgs> B_)
         int* bo = a.binOut + (size_t)s * VB_NB;
         int v[PER], sum = 0;
 #pragma unroll
-        for (int j = 0; j < PER; j++) { const int b = threadIdx.x * PER + j; v[j] = b < nbins ? bv[b] : 0; sum += v[j]; }
+        for (int j = 0; j < PER; j++) v[j] = bv[min((int)threadIdx.x * PER + j, VB_NB - 1)];            // all 16 loads in flight, masked below
+#pragma unroll
+        for (int j = 0; j < PER; j++) { const int b = threadIdx.x * PER + j; v[j] = b < nbins ? v[j] : 0; sum += v[j]; }
         int tot;
         int ex = block_excl_scan<256>(sum, ws, &tot);
 #pragma unroll
