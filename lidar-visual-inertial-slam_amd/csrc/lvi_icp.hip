@@ -244,8 +244,9 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         int tcap = (nrows + G - 1) / G;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tcap = max(tcap, __shfl_xor(tcap, o, 64));
+        int rbv[KNN_RPL], rev[KNN_RPL]; bool okv[KNN_RPL];
 #pragma unroll
-        for (int t = 0; t < KNN_RPL; t++) { off[t] = 0; st[t + 1] = 0; }
+        for (int t = 0; t < KNN_RPL; t++) { rbv[t] = 0; rev[t] = 0; okv[t] = false; }
 #pragma unroll
         for (int t = 0; t < KNN_RPL; t++) {
             if (t < tcap) {                                 // wave-uniform: a scalar branch, the loop stays unrolled
@@ -266,11 +267,13 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 const int x0 = max(cx + (int)floorf(tx - sx), 0), x1 = min(cx + (int)floorf(tx + sx), m.dim[0] - 1);
                 ok = ok && x0 <= x1;
                 const int row = ok ? (z * m.dim[1] + y) * m.dim[0] : 0;
-                const int rb = cell_start[row + (ok ? x0 : 0)];
-                const int re = cell_start[row + (ok ? x1 : 0) + 1];
-                off[t] = ok ? rb : 0; st[t + 1] = ok ? re - rb : 0;
+                rbv[t] = cell_start[row + (ok ? x0 : 0)];          // consumed after the loop: nothing in here waits for a load
+                rev[t] = cell_start[row + (ok ? x1 : 0) + 1];
+                okv[t] = ok;
             }
         }
+#pragma unroll
+        for (int t = 0; t < KNN_RPL; t++) { off[t] = okv[t] ? rbv[t] : 0; st[t + 1] = okv[t] ? rev[t] - rbv[t] : 0; }
 #pragma unroll
         for (int t = 0; t < KNN_RPL; t++) { const int len = st[t + 1]; st[t + 1] = st[t] + len; off[t] -= st[t]; }
         const int T = st[KNN_RPL];
