@@ -92,12 +92,17 @@ __global__ __launch_bounds__(256) void org_count_kernel(Batch<OrgArgs> B_)
     __syncthreads();
     const int base = blockIdx.x * ORG_TILE;
     int first = 0x7fffffff;
+    lvi_livox_pt q[ORG_TILE / 256];                     // unconditional loads (clamped index): the tile's points in flight together
+    if (a.n_raw > 0) {                                  // (an empty scan still writes its zero counts below)
+#pragma unroll
+        for (int j = 0; j < ORG_TILE / 256; j++) q[j] = a.raw[min(base + j * 256 + (int)threadIdx.x, a.n_raw - 1)];
+    }
 #pragma unroll
     for (int j = 0; j < ORG_TILE / 256; j++) {
         const int i = base + j * 256 + threadIdx.x;
         if (i < a.n_raw) {
             float r;
-            const int ring = org_classify(a, a.raw[i], &r);
+            const int ring = org_classify(a, q[j], &r);
             if (ring >= 0) { atomicAdd(&cnt[ring], 1); first = min(first, i); }
         }
     }
@@ -181,12 +186,20 @@ __global__ __launch_bounds__(256) void org_scatter_kernel(Batch<OrgArgs> B_)
     const uint64_t lt = lanemask_lt();
     constexpr int IT = ORG_TILE / NW / 64;
     lvi_pt p[IT]; float rg[IT]; int ring[IT]; int rk[IT];
+    if (a.n_raw <= 0) return;
+    lvi_livox_pt qs[IT];                                // unconditional loads (clamped index): the wavefront's points in flight together
+#pragma unroll
+    for (int j = 0; j < IT; j++) qs[j] = a.raw[min(cbase + j * 64 + l, a.n_raw - 1)];
+    // destination base of every ring for this tile (columnIdnCountVec before the tile + the ring's start): one lookup per point
+    __shared__ int ringDst[MAX_N_SCAN];
+    __shared__ int ringBaseS[MAX_N_SCAN];
+    if (threadIdx.x < a.N_SCAN) { ringDst[threadIdx.x] = a.blockCnt[threadIdx.x * a.nblk + blockIdx.x]; ringBaseS[threadIdx.x] = a.ringBase[threadIdx.x]; }
 #pragma unroll
     for (int j = 0; j < IT; j++) {
         const int i = cbase + j * 64 + l;
         ring[j] = -1; rk[j] = 0;
         if (i < a.n_raw) {
-            const lvi_livox_pt q = a.raw[i];
+            const lvi_livox_pt q = qs[j];
             ring[j] = org_classify(a, q, &rg[j]);
             p[j].x = q.x; p[j].y = q.y; p[j].z = q.z; p[j].intensity = (float)q.reflectivity;      // :254
         }
@@ -214,9 +227,9 @@ __global__ __launch_bounds__(256) void org_scatter_kernel(Batch<OrgArgs> B_)
 #pragma unroll
     for (int j = 0; j < IT; j++) {
         if (ring[j] < 0) continue;
-        const int colIdn = a.blockCnt[ring[j] * a.nblk + blockIdx.x] + waveCnt[w][ring[j]] + rk[j];   // columnIdnCountVec (:604-605)
+        const int colIdn = ringDst[ring[j]] + waveCnt[w][ring[j]] + rk[j];                             // columnIdnCountVec (:604-605)
         if (colIdn >= a.H) continue;                                                                   // :609
-        const int dst = a.ringBase[ring[j]] + colIdn;
+        const int dst = ringBaseS[ring[j]] + colIdn;
         if (a.dk_on) {
             const int i = cbase + j * 64 + l;
             float rot[3], R[3][3], M[3][3];
