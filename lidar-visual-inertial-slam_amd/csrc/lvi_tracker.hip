@@ -457,16 +457,23 @@ __global__ __launch_bounds__(256) void gftt_thr_kernel(GfttArgs a, int npartial)
 
 __device__ __forceinline__ bool gftt_is_cand(const GfttArgs& a, int x, int y, float thr)
 {
-    if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) return false;
-    const float* e = a.eig + (size_t)y * a.w + x;
-    const float val = e[0];
-    if (!(val > thr) || val == 0.f) return false;
-    if (a.mask && !a.mask[(size_t)y * a.w + x]) return false;
+    // the 3 x 3 neighbourhood and the mask byte are loaded unconditionally (coordinates clamped into the interior) and tested
+    // afterwards: with the tests in between, a pixel was up to ten round trips in a row
+    const int xc = min(max(x, 1), a.w - 2), yc = min(max(y, 1), a.h - 2);
+    const float* e = a.eig + (size_t)yc * a.w + xc;
+    float nv[9];
 #pragma unroll
     for (int j = -1; j <= 1; j++)
 #pragma unroll
-        for (int i = -1; i <= 1; i++) { const float nv = e[j * a.w + i]; if (nv > thr && nv > val) return false; }
-    return true;
+        for (int i = -1; i <= 1; i++) nv[(j + 1) * 3 + (i + 1)] = e[j * a.w + i];
+    const uint8_t mk = a.mask ? a.mask[(size_t)yc * a.w + xc] : (uint8_t)1;
+    if (x < 1 || y < 1 || x >= a.w - 1 || y >= a.h - 1) return false;
+    const float val = nv[4];
+    if (!(val > thr) || val == 0.f || !mk) return false;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) ok = ok && !(nv[k] > thr && nv[k] > val);
+    return ok;
 }
 
 constexpr int CAND_TILE = 1024;
