@@ -843,7 +843,7 @@ int32_t lvi_scan_to_map(lvi_lidar* h, const lvi_pt* corner, int32_t nc, const lv
                         const lvi_imu_hint* imu, float pose[6], lvi_icp_result* out)
 {
     if (!h || nc < 0 || ns < 0 || (nc > 0 && !corner) || (ns > 0 && !surf)) return fail(LVI_ERR_INVALID_ARG, "bad arguments");
-    if (nc > h->cur().ext_cap || ns > h->cur().ext_cap) return fail(LVI_ERR_CAPACITY, "feature clouds exceed capacity");
+    if (nc > h->cur().ext_cap || ns > h->cur().ext_cap || (long long)nc + ns > h->cur().ext_cap) return fail(LVI_ERR_CAPACITY, "feature clouds exceed capacity (corner + surf <= N_SCAN * Horizon_SCAN)");
     int32_t st = guarded(h, [&]() -> int32_t {
         LidarDev& d = h->cur();
         h2d(d, d.corner, corner, (size_t)nc); h2d(d, d.surf, surf, (size_t)ns);

@@ -471,20 +471,28 @@ struct IcpArgs {
     const lvi_pt* q[2]; const int* nq;            // cornerDS / surfDS, voxScan.d_nout
     const GridIndex::Meta* meta[2]; const int* cell_start[2]; const lvi_pt* sorted[2];
     const lvi_pt* mapds[2];
-    lvi_pt* coeff; uint8_t* flag; double* partial;
     int edgeMin, surfMin, max_iters, disable_break;
     float rot_tol, z_tol; double imu_weight;
     int imu_available; float imu_roll, imu_pitch;
     void* d_record;
     long long* cyc;
     const int* d_status;                          // [2] device error words: scan side, map build
-    const float* pose_init;                       // [6] initial guess (device)
     int have_map;
-    int* nn_prev;                                 // [Q][5] neighbours of the previous iteration (-1: fewer than five within 1 m)
-    float4* nn_ref;                               // [Q] where the feature stood at its last search (xyz) and a lower bound (w, squared) on the distance from there
-                                                  // to every map point outside its five; nullptr: search in every iteration
+    // per-feature records of the Gauss-Newton loop, structure of arrays with stride `cap` (one lane per feature reads them coalesced)
+    int cap;
+    int* nn_prev;                                 // [5][cap] the five neighbours of the feature's last search, in the (distance, index) order its FIT was made for
+                                                  //          ([0][t] = -1: fewer than five within 1 m); nullptr: every iteration searches the whole unit ball
+    float4* nn_pt;                                // [5][cap] their coordinates (xyz), same order: the skip test, the order test and the fit read no map point
+    float4* nn_ref;                               // [cap] where the feature stood at its last search (xyz) and a lower bound (w, squared) on the distance from there
+                                                  //       to every map point outside its five; nullptr: search in every iteration
+    float4* fit;                                  // [cap] surf: the plane (pa, pb, pc, pd); corner: the first line point
+    float4* fit2;                                 // [cap] corner: the second line point
+    unsigned char* fit_ok;                        // [cap] 0: no fit stored; 1: stored, geometric gate passed; 2: stored, gate failed
     float knn_slack;                              // metres added to the radius of a bounded search (room for later iterations to skip theirs)
     int xcd_map;                                  // residual workgroups are dealt to the XCDs in contiguous feature ranges (LVI_ICP_NO_XCD_MAP=1: in launch order)
+    // normal equations: 28 columns x {coarse, fine} exact fixed-point accumulators + the arrival ticket of the launch
+    unsigned long long* acc;                      // [56], zero between launches (the last arriver takes them with an exchange)
+    unsigned* ticket;                             // [1], zero between launches
 };
 
 __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
@@ -497,14 +505,15 @@ __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)    
     return o;
 }
 
-__device__ bool corner_residual(const IcpArgs& a, const lvi_pt& pointSel, const Knn5& r, lvi_pt& coeff)
+// cornerOptimization (:1006-1096) in two halves.  The FIT depends on the five neighbours alone (their coordinates and their
+// order): centroid, covariance, cv::eigen, the eigenvalue gate and the two points on the line.  The EVALUATION takes the
+// feature's current position.  A Gauss-Newton iteration whose five neighbours and their order did not change re-uses the fit
+// of the previous one: the same bits as fitting again.
+__device__ __forceinline__ bool corner_fit(const lvi_pt nb[5], float4& l1, float4& l2)
 {
-    if (!(r.d[4] < 1.0f)) return false;                                            // :1025
-    const lvi_pt* map = a.mapds[0];
     float cx = 0, cy = 0, cz = 0;
-    lvi_pt nb[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { nb[j] = map[r.i[j]]; cx += nb[j].x; cy += nb[j].y; cz += nb[j].z; }
+    for (int j = 0; j < 5; j++) { cx += nb[j].x; cy += nb[j].y; cz += nb[j].z; }
     cx /= 5; cy /= 5; cz /= 5;
     float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
 #pragma unroll
@@ -515,10 +524,15 @@ __device__ bool corner_residual(const IcpArgs& a, const lvi_pt& pointSel, const 
     a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
     float ev[3], v0[3];
     eig3_sym(a11, a12, a13, a22, a23, a33, ev, v0);                                // cv::eigen :1050
-    if (!(ev[0] > 3 * ev[1])) return false;
-    const float x0 = pointSel.x, y0 = pointSel.y, z0 = pointSel.z;
     const float x1 = cx + 0.1 * v0[0], y1 = cy + 0.1 * v0[1], z1 = cz + 0.1 * v0[2];
     const float x2 = cx - 0.1 * v0[0], y2 = cy - 0.1 * v0[1], z2 = cz - 0.1 * v0[2];
+    l1 = make_float4(x1, y1, z1, 0.f); l2 = make_float4(x2, y2, z2, 0.f);
+    return ev[0] > 3 * ev[1];
+}
+__device__ __forceinline__ bool corner_eval(const float4& l1, const float4& l2, const lvi_pt& pointSel, lvi_pt& coeff)
+{
+    const float x0 = pointSel.x, y0 = pointSel.y, z0 = pointSel.z;
+    const float x1 = l1.x, y1 = l1.y, z1 = l1.z, x2 = l2.x, y2 = l2.y, z2 = l2.z;
     const float m11 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
     const float m12 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
     const float m13 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
@@ -532,26 +546,54 @@ __device__ bool corner_residual(const IcpArgs& a, const lvi_pt& pointSel, const 
     coeff.x = s * la; coeff.y = s * lb; coeff.z = s * lc; coeff.intensity = s * ld2;
     return s > 0.1;
 }
-
-__device__ bool surf_residual(const IcpArgs& a, const lvi_pt& pointOri, const lvi_pt& pointSel, const Knn5& r, lvi_pt& coeff)
+__device__ bool corner_residual(const IcpArgs& a, const lvi_pt& pointSel, const Knn5& r, lvi_pt& coeff)
 {
-    if (!(r.d[4] < 1.0f)) return false;                                            // :1121
-    const lvi_pt* map = a.mapds[1];
-    float M[5][3], b[5], X[3];
+    if (!(r.d[4] < 1.0f)) return false;                                            // :1025
+    const lvi_pt* map = a.mapds[0];
     lvi_pt nb[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { nb[j] = map[r.i[j]]; M[j][0] = nb[j].x; M[j][1] = nb[j].y; M[j][2] = nb[j].z; b[j] = -1.f; }
+    for (int j = 0; j < 5; j++) nb[j] = map[r.i[j]];
+    float4 l1, l2;
+    if (!corner_fit(nb, l1, l2)) return false;
+    return corner_eval(l1, l2, pointSel, coeff);
+}
+
+// surfOptimization (:1098-1167), the same two halves: the plane through the five neighbours and its 0.2 m gate / the feature's
+// distance from it
+__device__ __forceinline__ bool surf_fit(const lvi_pt nb[5], float4& pl)
+{
+    float M[5][3], b[5], X[3];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { M[j][0] = nb[j].x; M[j][1] = nb[j].y; M[j][2] = nb[j].z; b[j] = -1.f; }
     lstsq_5x3(M, b, X);                                                            // colPivHouseholderQr().solve :1128
     float pa = X[0], pb = X[1], pc = X[2], pd = 1;
     const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
     pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+    bool valid = true;
 #pragma unroll
     for (int j = 0; j < 5; j++)
-        if (fabsf(pa * nb[j].x + pb * nb[j].y + pc * nb[j].z + pd) > 0.2) return false;
+        if (fabsf(pa * nb[j].x + pb * nb[j].y + pc * nb[j].z + pd) > 0.2) valid = false;
+    pl = make_float4(pa, pb, pc, pd);
+    return valid;
+}
+__device__ __forceinline__ bool surf_eval(const float4& pl, const lvi_pt& pointOri, const lvi_pt& pointSel, lvi_pt& coeff)
+{
+    const float pa = pl.x, pb = pl.y, pc = pl.z, pd = pl.w;
     const float pd2 = pa * pointSel.x + pb * pointSel.y + pc * pointSel.z + pd;
     const float s = 1 - 0.9 * fabsf(pd2) / sqrtf(sqrtf(pointOri.x * pointOri.x + pointOri.y * pointOri.y + pointOri.z * pointOri.z));
     coeff.x = s * pa; coeff.y = s * pb; coeff.z = s * pc; coeff.intensity = s * pd2;
     return s > 0.1;
+}
+__device__ bool surf_residual(const IcpArgs& a, const lvi_pt& pointOri, const lvi_pt& pointSel, const Knn5& r, lvi_pt& coeff)
+{
+    if (!(r.d[4] < 1.0f)) return false;                                            // :1121
+    const lvi_pt* map = a.mapds[1];
+    lvi_pt nb[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) nb[j] = map[r.i[j]];
+    float4 pl;
+    if (!surf_fit(nb, pl)) return false;
+    return surf_eval(pl, pointOri, pointSel, coeff);
 }
 
 // one Gauss-Newton row: matA(i, 0..5), matB(i) (LMOptimization :1224-1255)
@@ -572,183 +614,6 @@ __device__ __forceinline__ void lm_row(const float tr[6], const lvi_pt& ori, con
     rowB = -cf.intensity;
 }
 
-constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup (64: the residual phase fills its wavefront)
-static_assert(ICP_QPB <= 64, "the residual phase runs on one wavefront");
-
-// Three phases per workgroup of 64 features (64 G threads):
-//   0  first wavefront, one lane per feature: the skip test of the 5-NN search (see below); the features that search are listed
-//   A  G lanes per LISTED feature, packed to the front of the workgroup: transform + 5-NN; the merged neighbour lists go to LDS
-//   B  ONE wavefront, one lane per feature: line / plane fit, residual, Gauss-Newton row (6+1 values) and its
-//      27 products in f64, into LDS; then 28 threads add the 64 rows in fixed order → one partial per workgroup.
-// (Doing B inside the G-lane groups made every wavefront execute the whole eigen/QR code for a few active lanes.)
-// What a launch costs (clock64 stamps, one scan, Q = 22.6 k): a workgroup needs ~13 k cycles (6 us) when its features skip the
-// search and ~28 k when they all search, of a 20 us launch: every launch starts on cold L2s (a kernel boundary on this
-// multi-XCD part invalidates them: the counters show the 1.9 MB index re-fetched by every launch) and the phases are chains
-// of dependent gathers.  The chip's VALU issue capacity is not the limit (~3 k wave-instructions x 353 workgroups = 2 us of it).
-template <int G, int KB>
-__global__ __launch_bounds__(64 * G) void icp_residual_kernel(Batch<IcpArgs> B_)
-{
-    const IcpArgs& a = B_.a[blockIdx.z];
-    // everything the prologue needs is requested before the first value is tested (one round trip instead of four in a row)
-    const int done = a.st->done, iters_now = a.st->iters;
-    const int nC = a.nq[0], nS = a.nq[1];
-    const float poseA = threadIdx.x < 12 ? a.st->pose.A[threadIdx.x] : 0.f, poseT = threadIdx.x < 6 ? a.st->pose.trig[threadIdx.x] : 0.f;
-    if (done) return;
-    // XCD-aware placement (speed only): workgroups b and b + 8 share an XCD and its L2, so XCD k takes a CONTIGUOUS eighth of the
-    // features — they come in voxel order, a spatial slab — and its L2 fetches that slab's part of the index and the map instead
-    // of all of it (every launch starts on cold L2s: the counters showed each of the eight L2s re-fetching the whole index)
-    const int nb = (nC + nS + ICP_QPB - 1) / ICP_QPB;
-    const int per_xcd = (nb + 7) / 8;
-    const int wg = a.xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if ((a.xcd_map && (int)(blockIdx.x >> 3) >= per_xcd) || wg >= nb) return;
-    const bool stamp = (wg == (nC + nS) / ICP_QPB / 2 && threadIdx.x == 0);     // a surf workgroup in the middle
-    long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
-    __shared__ float sA[12], sT[6];
-    __shared__ double srow[ICP_QPB][28];
-    __shared__ Knn5 snn[ICP_QPB];
-    __shared__ float sr2[ICP_QPB];                  // search radius (squared) of the features that search, in list order
-    __shared__ unsigned char slist[ICP_QPB];        // the features (workgroup-local) that search in this iteration
-    __shared__ int snsearch;
-    if (threadIdx.x < 12) sA[threadIdx.x] = poseA;
-    if (threadIdx.x < 6) sT[threadIdx.x] = poseT;
-    __syncthreads();
-    // Phase 0, first wavefront, one lane per feature.  From the second iteration on a feature knows its previous five
-    // neighbours; their distances under the new pose bound the fifth-nearest distance (five map points lie inside that ball),
-    // and the search either shrinks to that ball or is not needed at all: the feature's last search left a lower bound LB on
-    // the distance from where it stood THEN (ref) to every map point outside its five, so every such point is at least
-    // LB - |sel - ref| away now; if that exceeds the farthest of the five (with 2e-4 m of room for the f32 rounding of the
-    // distances, 1e-6 relative), the five are still the five nearest, no outsider can even tie, and their (distance, index)
-    // order is recomputed here with the search's own expression: the same Knn5, bit for bit, without a search.
-    if (threadIdx.x < ICP_QPB) {
-        const int ql = threadIdx.x;
-        const int t = wg * ICP_QPB + ql;
-        const bool active = t < nC + nS;
-        bool need = active;
-        float r2 = KNN_R2_FULL;
-        if (active && a.nn_prev && iters_now > 0) {
-            const bool isC = t < nC;
-            const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
-            const lvi_pt sel = to_map(sA, ori);
-            const int* __restrict__ pn = a.nn_prev + (size_t)t * 5;
-            int id[5];
-#pragma unroll
-            for (int j = 0; j < 5; j++) id[j] = pn[j];
-            if (id[0] >= 0) {
-                const lvi_pt* __restrict__ map = a.mapds[isC ? 0 : 1];
-                KnnKeys kk;
-#pragma unroll
-                for (int j = 0; j < 5; j++) kk.k[j] = KNN_EMPTY;
-                float b = 0.f;
-#pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const lvi_pt p = map[id[j]];
-                    const float ex = sub_rn(sel.x, p.x), ey = sub_rn(sel.y, p.y), ez = sub_rn(sel.z, p.z);
-                    const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
-                    b = fmaxf(b, dist);
-                    knn_insert(kk, knn_key(dist, id[j]));
-                }
-                if (b < 1.0f) {
-                    const float rb = sqrtf(b);
-                    if (a.nn_ref) {
-                        const float4 ref = a.nn_ref[t];
-                        const float dx = sel.x - ref.x, dy = sel.y - ref.y, dz = sel.z - ref.z;
-                        if (rb + sqrtf(dx * dx + dy * dy + dz * dz) + 2e-4f < sqrtf(ref.w)) {
-                            Knn5 r;
-#pragma unroll
-                            for (int j = 0; j < 5; j++) { r.d[j] = __uint_as_float((unsigned)(kk.k[j] >> 32)); r.i[j] = (int)(unsigned)kk.k[j]; }
-                            snn[ql] = r;
-                            need = false;
-                        }
-                    }
-                    const float rs = rb + a.knn_slack;
-                    r2 = fminf(fmaxf(b, rs * rs), KNN_R2_FULL);
-                }
-            }
-        }
-        const unsigned long long mk = __ballot(need);
-        if (need) { const int pos = __popcll(mk & ((1ull << ql) - 1ull)); slist[pos] = (unsigned char)ql; sr2[pos] = r2; }
-        if (ql == 0) snsearch = __popcll(mk);
-    }
-    LVI_STAMP(0);
-    __syncthreads();
-    // Phase A: G lanes per SEARCHING feature, packed to the front of the workgroup (wavefronts beyond the list have nothing to do)
-    {
-        const int gi = threadIdx.x / G, sub = threadIdx.x % G;
-        long long tk[6] = {0, 0, 0, 0, 0, 0};
-        float r2 = KNN_R2_FULL;
-        if (gi < snsearch) {
-            const int ql = slist[gi];
-            const int t = wg * ICP_QPB + ql;
-            const bool isC = t < nC;
-            const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
-            const lvi_pt sel = to_map(sA, ori);
-            const int w = isC ? 0 : 1;
-            r2 = sr2[gi];
-            Knn5 r;
-            float lb2 = 0.f;
-            knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
-            if (sub == 0) {
-                snn[ql] = r;
-                if (a.nn_prev) {
-                    int* __restrict__ pn = a.nn_prev + (size_t)t * 5;
-                    const bool five = r.d[4] < 1.0f;
-#pragma unroll
-                    for (int j = 0; j < 5; j++) pn[j] = five ? r.i[j] : -1;
-                    if (a.nn_ref) a.nn_ref[t] = make_float4(sel.x, sel.y, sel.z, five ? lb2 : 0.f);
-                }
-            }
-        }
-        LVI_STAMP(1);
-        if (stamp) { cyc[6] = tk[1] - tk[0]; cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; a.cyc[13] = tk[5]; a.cyc[14] = r2 < KNN_R2_FULL ? 1 : 0; }
-        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&a.cyc[15], (unsigned long long)snsearch);      // searches of this scan match, all iterations
-    }
-    __syncthreads();
-    if (threadIdx.x < ICP_QPB) {
-        const int ql = threadIdx.x;
-        const int t = wg * ICP_QPB + ql;
-        double* row = srow[ql];
-        bool ok = false;
-        if (t < nC + nS) {
-            const bool isC = t < nC;
-            const lvi_pt ori = isC ? a.q[0][t] : a.q[1][t - nC];
-            const lvi_pt sel = to_map(sA, ori);
-            const Knn5 r = snn[ql];
-            lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
-            ok = isC ? corner_residual(a, sel, r, cf) : surf_residual(a, ori, sel, r, cf);
-            a.flag[t] = ok ? 1 : 0;
-            a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                float rA[6], rB;
-                lm_row(sT, ori, cf, rA, rB);
-                int k = 0;
-#pragma unroll
-                for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-                    for (int c = rr; c < 6; c++) row[k++] = (double)rA[rr] * (double)rA[c];
-#pragma unroll
-                for (int rr = 0; rr < 6; rr++) row[21 + rr] = (double)rA[rr] * (double)rB;
-                row[27] = 1.0;
-            }
-        }
-        if (!ok) {
-#pragma unroll
-            for (int k = 0; k < 28; k++) row[k] = 0.0;
-        }
-    }
-    LVI_STAMP(3);
-    __syncthreads();
-    if (threadIdx.x < 28) {                     // fixed summation order → bit-reproducible from run to run
-        double v = 0.0;
-#pragma unroll 8
-        for (int q = 0; q < ICP_QPB; q++) v += srow[q][threadIdx.x];
-        a.partial[(size_t)wg * 28 + threadIdx.x] = v;
-    }
-    LVI_STAMP(4);
-    if (stamp) { cyc[5] = clock64() - t_first; for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q]; }
-#undef LVI_STAMP
-}
-
 __device__ void make_pose(IcpPose& p)
 {
     // pcl::getTransformation(x,y,z,roll,pitch,yaw) (trans2Affine3f :404-407)
@@ -766,216 +631,24 @@ __device__ void make_pose(IcpPose& p)
     p.trig[4] = F; p.trig[5] = E;
 }
 
-struct PoseInitArgs { float* dst; float t[6]; int* d_status; };
+// The initial guess of a scan match and the reset of its Gauss-Newton state (what scan2MapOptimization starts from, :1315-1322):
+// one thread per batch slot.  The feature-count gates (:1317, :1320) are evaluated by the first Gauss-Newton launch, where the
+// counts of the scan's grids exist.
+struct PoseInitArgs { float* dst; float t[6]; int* d_status; IcpState* st; long long* cyc; unsigned long long* acc; unsigned* ticket; };
 __global__ void set_pose_init_kernel(Batch<PoseInitArgs> B_)
 {
     const PoseInitArgs& a = B_.a[blockIdx.z];
 #pragma unroll
     for (int k = 0; k < 6; k++) a.dst[k] = a.t[k];
     if (a.d_status) a.d_status[0] = 0;            // scan-side device status word of a batch slot (single scans: cleared by the upload)
-}
-
-__global__ void icp_init_kernel(Batch<IcpArgs> B_)
-{
-    const IcpArgs& a = B_.a[blockIdx.z];
-    const float* __restrict__ pose_init = a.pose_init;
-    const int have_map = a.have_map;
     IcpState& s = *a.st;
-    for (int k = 0; k < 6; k++) s.pose.T[k] = pose_init[k];
+    for (int k = 0; k < 6; k++) s.pose.T[k] = a.t[k];
     make_pose(s.pose);
-    s.done = 0; s.converged = 0; s.iters = 0; s.any_lm = 0; s.status = LVI_OK;
-    a.cyc[15] = 0;                                 // searches counted by the residual kernel (debug read-out)
+    s.done = 0; s.converged = 0; s.degenerate = 0; s.iters = 0; s.any_lm = 0; s.status = LVI_OK;
+    a.cyc[15] = 0;                                 // searches counted by the Gauss-Newton kernel (debug read-out)
     for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) s.n_sel[i] = 0;
-    if (!have_map) { s.done = 1; s.status = LVI_NO_MAP; return; }                              // :1317
-    if (!(a.nq[0] > a.edgeMin && a.nq[1] > a.surfMin)) { s.done = 1; s.status = LVI_TOO_FEW_FEATURES; }   // :1320
-}
-
-// Householder QR solve of the 6x6 system (cv::solve DECOMP_QR, :1260), f32
-__device__ bool solve6_qr(float A[6][6], float b[6])
-{
-    // fully unrolled: every index is a compile-time constant, so A, b and the Householder vector stay in registers
-#pragma unroll
-    for (int l = 0; l < 6; l++) {
-        float vl[6];
-        float nrm = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) if (i >= l) { vl[i] = A[i][l]; nrm += vl[i] * vl[i]; }
-        const float t0 = vl[l];
-        vl[l] = vl[l] + (vl[l] >= 0.f ? 1.f : -1.f) * sqrtf(nrm);
-        nrm = sqrtf(nrm + vl[l] * vl[l] - t0 * t0);
-        if (nrm == 0.f) return false;
-#pragma unroll
-        for (int i = 0; i < 6; i++) if (i >= l) vl[i] /= nrm;
-#pragma unroll
-        for (int j = 0; j < 6; j++) if (j >= l) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 6; i++) if (i >= l) s += vl[i] * A[i][j];
-#pragma unroll
-            for (int i = 0; i < 6; i++) if (i >= l) A[i][j] -= 2 * vl[i] * s;
-        }
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) if (i >= l) s += vl[i] * b[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) if (i >= l) b[i] -= 2 * vl[i] * s;
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; i--) {
-#pragma unroll
-        for (int j = 5; j >= 0; j--) if (j > i) b[i] -= b[j] * A[i][j];
-        if (fabsf(A[i][i]) < 1.1920929e-6f) return false;
-        b[i] /= A[i][i];
-    }
-    return true;
-}
-
-// symmetric 6x6 eigen-decomposition (cv::eigen :1268), cyclic Jacobi f32; W descending, rows of V = eigenvectors
-// (every index is a compile-time constant after unrolling: A and V stay in registers; with runtime indices they
-// lived in scratch memory and iteration 0 of the solve kernel took 80 us)
-__device__ void eig6_sym(float A[6][6], float W[6], float V[6][6])
-{
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.f : 0.f;
-    for (int sweep = 0; sweep < 30; sweep++) {
-        float off = 0.f, dia = 0.f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) { dia += fabsf(A[i][i]);
-#pragma unroll
-            for (int j = i + 1; j < 6; j++) off += fabsf(A[i][j]); }
-        if (off <= 1e-10f * dia || off == 0.f) break;
-#pragma unroll
-        for (int p = 0; p < 5; p++)
-#pragma unroll
-            for (int q = p + 1; q < 6; q++) {
-                const float apq = A[p][q];
-                if (apq == 0.f) continue;
-                const float theta = (A[q][q] - A[p][p]) / (2.f * apq);
-                const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
-                const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
-                A[p][p] -= t * apq; A[q][q] += t * apq; A[p][q] = A[q][p] = 0.f;
-#pragma unroll
-                for (int r = 0; r < 6; r++) {
-                    if (r == p || r == q) continue;
-                    const float arp = A[r][p], arq = A[r][q];
-                    A[r][p] = A[p][r] = c * arp - s * arq;
-                    A[r][q] = A[q][r] = s * arp + c * arq;
-                }
-#pragma unroll
-                for (int k = 0; k < 6; k++) { const float vp = V[p][k], vq = V[q][k]; V[p][k] = c * vp - s * vq; V[q][k] = s * vp + c * vq; }
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) W[i] = A[i][i];
-    // descending selection sort with compile-time positions: the swap partner is selected by value, not by index
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-#pragma unroll
-        for (int i = k + 1; i < 6; i++) {
-            // bubble the maximum of W[k..5] into position k: equivalent to "m = argmax (first on ties), swap(k, m)" up to
-            // the order of the remaining entries, which later rounds fix; rows of V follow their eigenvalue
-            if (W[k] < W[i]) {
-                const float t = W[i]; W[i] = W[k]; W[k] = t;
-#pragma unroll
-                for (int c = 0; c < 6; c++) { const float u = V[i][c]; V[i][c] = V[k][c]; V[k][c] = u; }
-            }
-        }
-    }
-}
-
-constexpr int SOLVE_THREADS = 256;      // 1024 threads cap the kernel at 128 VGPRs (the 6x6 matrices of the serial part spill); 512 x 256 VGPRs need a completely idle CU (26 us under load); 256: 18 us
-__device__ void icp_finish_body(const IcpArgs& a);      // transformUpdate + the pose record, defined below
-
-__device__ __forceinline__ void icp_solve_body(const IcpArgs& a, int iter)
-{
-    IcpState& s = *a.st;
-    if (s.done) return;
-    const long long tq0 = clock64();
-    __shared__ double part[SOLVE_THREADS / 32][28];
-    __shared__ double sums[28];
-    const int Q = a.nq[0] + a.nq[1];
-    const int nb = (Q + ICP_QPB - 1) / ICP_QPB;
-    {   // 32 groups x 28 columns, each group strides over the workgroup partials; then a fixed-order combine
-        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-        if (k < 28) {
-            double v = 0.0;
-            constexpr int GS = SOLVE_THREADS / 32;
-            constexpr int NLD = 24;                                     // loads in flight per lane (347 partials / 16 groups = 22 rows)
-            for (int b0 = g; b0 < nb; b0 += NLD * GS) {                 // summed in the fixed order b0, b0+GS, …
-                double t[NLD];
-#pragma unroll
-                for (int u = 0; u < NLD; u++) { const int b = b0 + u * GS; t[u] = b < nb ? a.partial[(size_t)b * 28 + k] : 0.0; }
-#pragma unroll
-                for (int u = 0; u < NLD; u++) v += t[u];
-            }
-            part[g][k] = v;
-        }
-    }
-    __syncthreads();
-    const long long tq1 = clock64();
-    if (threadIdx.x < 28) {
-        double v = 0.0;
-        for (int g = 0; g < SOLVE_THREADS / 32; g++) v += part[g][threadIdx.x];
-        sums[threadIdx.x] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    const long long tq2 = clock64();
-    const int nsel = (int)sums[27];
-    s.n_sel[iter] = nsel;
-    s.iters = iter + 1;
-    for (int k = 0; k < 6; k++) s.pose_trace[iter * 6 + k] = s.pose.T[k];
-    for (int k = 0; k < 27; k++) s.jtj[iter * 27 + k] = (float)sums[k];
-    if (nsel >= 50) {                                                            // :1210
-        s.any_lm = 1;
-        float AtA[6][6], X[6];
-        {
-            int k = 0;
-            for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { AtA[r][c] = AtA[c][r] = (float)sums[k++]; }
-            for (int r = 0; r < 6; r++) X[r] = (float)sums[21 + r];
-        }
-        {
-            float Ac[6][6];
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Ac[r][c] = AtA[r][c];
-            if (!solve6_qr(Ac, X)) for (int r = 0; r < 6; r++) X[r] = 0.f;
-        }
-        float matP[6][6];
-        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) matP[r][c] = 0.f;  // local matP shadows the member
-        if (iter == 0) {
-            float W[6], V[6][6], V2[6][6], Ac[6][6];
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Ac[r][c] = AtA[r][c];
-            eig6_sym(Ac, W, V);
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) V2[r][c] = V[r][c];
-            s.degenerate = 0;
-            for (int i = 5; i >= 0; i--) {
-                if (W[i] < 100.f) { for (int j = 0; j < 6; j++) V2[i][j] = 0.f; s.degenerate = 1; }
-                else break;
-            }
-            // matP = matV.inv() * matV2; V is orthogonal, inv(V) = V^T
-            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { double acc = 0; for (int k = 0; k < 6; k++) acc += (double)V[k][r] * (double)V2[k][c]; matP[r][c] = (float)acc; }
-        }
-        if (s.degenerate) {
-            float X2[6];
-            for (int r = 0; r < 6; r++) X2[r] = X[r];
-            for (int r = 0; r < 6; r++) { double acc = 0; for (int k = 0; k < 6; k++) acc += (double)matP[r][k] * (double)X2[k]; X[r] = (float)acc; }
-        }
-        for (int r = 0; r < 6; r++) s.pose.T[r] += X[r];
-        // pow(x, 2) of the reference is the correctly rounded double square
-        const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
-        const double u0 = (double)(X[3] * 100), u1 = (double)(X[4] * 100), u2 = (double)(X[5] * 100);
-        const double dR = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-        const double dT = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
-        const float deltaR = (float)dR, deltaT = (float)dT;
-        if (deltaR < 0.05 && deltaT < 0.05) {                                    // :1309
-            s.converged = 1;
-            if (!a.disable_break) s.done = 1;
-        }
-        const long long tq3 = clock64();
-        make_pose(s.pose);
-        if (a.cyc && iter == 1) { const long long tq4 = clock64(); a.cyc[8] = tq1 - tq0; a.cyc[9] = tq2 - tq1; a.cyc[10] = tq3 - tq2; a.cyc[11] = tq4 - tq3; a.cyc[12] = tq4 - tq0; }
-    }
+    for (int k = 0; k < 56; k++) a.acc[k] = 0ull;  // (zero already unless a launch sequence was cut short)
+    *a.ticket = 0u;
 }
 
 // tf2 pieces of transformUpdate (doubles)
@@ -1009,16 +682,7 @@ __device__ void q_to_rpy(const Quatd& q, double& roll, double& pitch, double& ya
     else { pitch = -asin(m20); roll = atan2(m21 / cos(pitch), m22 / cos(pitch)); yaw = atan2(m10 / cos(pitch), m00 / cos(pitch)); }
 }
 
-// the last iteration's solve launch also finishes the scan (one launch less on the critical path)
-__global__ __launch_bounds__(SOLVE_THREADS) void icp_solve_kernel(Batch<IcpArgs> B_, int iter, int last)
-{
-    const IcpArgs& a = B_.a[blockIdx.z];
-    icp_solve_body(a, iter);                    // threads other than 0 come back early
-    if (last && threadIdx.x == 0) icp_finish_body(a);
-}
-
-__global__ void icp_finish_kernel(Batch<IcpArgs> B_) { icp_finish_body(B_.a[blockIdx.z]); }       // only launched when icp_max_iters == 0
-
+// transformUpdate (:1345-1375) and the 32-byte pose record of the scan: one lane, at the end of the last launch
 __device__ void icp_finish_body(const IcpArgs& a)
 {
     IcpState& s = *a.st;
@@ -1046,6 +710,532 @@ __device__ void icp_finish_body(const IcpArgs& a)
     s.record.status = s.status; s.record.iters = s.iters;
     if (a.d_record) *reinterpret_cast<lvi_pose_record*>(a.d_record) = s.record;
 }
+__global__ void icp_finish_kernel(Batch<IcpArgs> B_)       // only launched when icp_max_iters == 0
+{
+    const IcpArgs& a = B_.a[blockIdx.z];
+    IcpState& s = *a.st;
+    if (!a.have_map) s.status = LVI_NO_MAP;                                                           // :1317
+    else if (!(a.nq[0] > a.edgeMin && a.nq[1] > a.surfMin)) s.status = LVI_TOO_FEW_FEATURES;          // :1320
+    icp_finish_body(a);
+}
+
+// ------------------------------------------------------------------------------------------- the 6 x 6 end of an iteration, on ONE wavefront
+// Lane j < 6 holds column j of the symmetric 6 x 6 matrix, lane 6 the right-hand side; values that every lane needs are read
+// across with v_readlane (compile-time lane and register): a few dozen registers instead of the ~250 of the all-in-one-lane form,
+// which is what lets the solve live at the end of the Gauss-Newton kernel.  Control flow is wave-uniform throughout.
+__device__ __forceinline__ float rdl(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// Householder QR solve of the 6x6 system (cv::solve DECOMP_QR, :1260), f32: c[i] = A[i][lane] for lane < 6, = b[i] on lane 6.
+// Returns false when the matrix is singular to working precision; X (every lane) = the solution.  Same operations in the
+// same order as the column-by-column scalar form.
+__device__ __forceinline__ bool solve6_qr_wave(float c[6], int lane, float X[6])
+{
+    bool ok = true;
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+        float vl[6];
+        float nrm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i >= l) { vl[i] = rdl(c[i], l); nrm += vl[i] * vl[i]; }
+        const float t0 = vl[l];
+        vl[l] = vl[l] + (vl[l] >= 0.f ? 1.f : -1.f) * sqrtf(nrm);
+        nrm = sqrtf(nrm + vl[l] * vl[l] - t0 * t0);
+        if (nrm == 0.f) { ok = false; nrm = 1.f; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i >= l) vl[i] /= nrm;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i >= l) s += vl[i] * c[i];
+        if (lane >= l) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) if (i >= l) c[i] -= 2 * vl[i] * s;
+        }
+    }
+    float b[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) b[i] = rdl(c[i], 6);
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+#pragma unroll
+        for (int j = 5; j >= 0; j--) if (j > i) b[i] -= b[j] * rdl(c[i], j);
+        const float d = rdl(c[i], i);
+        if (fabsf(d) < 1.1920929e-6f) ok = false;
+        b[i] /= d;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) X[i] = b[i];
+    return ok;
+}
+
+// Is every eigenvalue of the symmetric 6 x 6 matrix (the f32 AtA, upper triangle in sums[0..20]) above sigma?  LDL^T of
+// A - sigma I in double: all pivots positive <=> yes.  Uniform scalar code (every lane computes the same).
+__device__ __forceinline__ bool all_eig_above(const double* sums, double sigma)
+{
+    double L[6][6], d[6];
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double dj = (double)(float)sums[j * 6 - (j * (j - 1)) / 2] - sigma;
+#pragma unroll
+        for (int k = 0; k < 6; k++) if (k < j) dj -= L[j][k] * L[j][k] * d[k];
+        d[j] = dj;
+        if (!(dj > 0.0)) { pd = false; d[j] = 1.0; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (i > j) {
+            double v = (double)(float)sums[j * 6 - (j * (j - 1)) / 2 + (i - j)];
+#pragma unroll
+            for (int k = 0; k < 6; k++) if (k < j) v -= L[i][k] * L[j][k] * d[k];
+            L[i][j] = v / d[j];
+        }
+    }
+    return pd;
+}
+
+// Symmetric 6x6 eigen-decomposition (cv::eigen :1268), cyclic Jacobi f32 on one wavefront: ac[i] = A[i][lane], vc[i] = V[i][lane]
+// (rows of V = eigenvectors).  On return W (every lane) holds the eigenvalues, descending, the rows of V follow.
+__device__ __forceinline__ void eig6_wave(float ac[6], float vc[6], int lane, float W[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) vc[i] = (i == lane) ? 1.f : 0.f;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        float off_l = 0.f, dia_l = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { off_l += (i < lane) ? fabsf(ac[i]) : 0.f; dia_l += (i == lane) ? fabsf(ac[i]) : 0.f; }
+        float off = 0.f, dia = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { off += rdl(off_l, j); dia += rdl(dia_l, j); }
+        if (off <= 1e-10f * dia || off == 0.f) break;
+#pragma unroll
+        for (int p = 0; p < 5; p++)
+#pragma unroll
+            for (int q = p + 1; q < 6; q++) {
+                const float apq = rdl(ac[p], q);
+                if (apq == 0.f) continue;
+                const float app = rdl(ac[p], p), aqq = rdl(ac[q], q);
+                const float theta = (aqq - app) / (2.f * apq);
+                const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+                const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+                // lanes r != p, q: rows p and q of their column (A[p][r] = A[r][p] by symmetry)
+                const float arp = ac[p], arq = ac[q];
+                const float np = c * arp - s * arq, nq = s * arp + c * arq;
+                if (lane != p && lane != q) { ac[p] = np; ac[q] = nq; }
+                // columns p and q receive the new A[r][p], A[r][q]
+#pragma unroll
+                for (int r = 0; r < 6; r++) if (r != p && r != q) {
+                    const float vp_ = rdl(ac[p], r), vq_ = rdl(ac[q], r);
+                    if (lane == p) ac[r] = vp_;
+                    if (lane == q) ac[r] = vq_;
+                }
+                if (lane == p) { ac[p] = app - t * apq; ac[q] = 0.f; }
+                if (lane == q) { ac[q] = aqq + t * apq; ac[p] = 0.f; }
+                const float vp = vc[p], vq = vc[q];
+                vc[p] = c * vp - s * vq; vc[q] = s * vp + c * vq;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) W[i] = rdl(ac[i], i);
+    // descending order, rows of V follow their eigenvalue (W is the same in every lane: uniform branches)
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            if (W[k] < W[i]) {
+                const float t = W[i]; W[i] = W[k]; W[k] = t;
+                const float u = vc[i]; vc[i] = vc[k]; vc[k] = u;
+            }
+        }
+    }
+}
+
+// combineOptimizationCoeffs + LMOptimization past the row products (:1169-1313), transformUpdate when this was the last
+// iteration: the first wavefront of the workgroup whose ticket was the last of the launch.  sums[28] (LDS): the 21 + 6 sums
+// of AtA / AtB and the number of selected rows.
+__device__ __forceinline__ void icp_solve_tail(const IcpArgs& a, int iter, int last, const double* sums)
+{
+    IcpState& s = *a.st;
+    const int lane = threadIdx.x;                                                 // < 64
+    const int nsel = (int)sums[27];
+    if (lane == 0) {
+        s.n_sel[iter] = nsel;
+        s.iters = iter + 1;
+        for (int k = 0; k < 6; k++) s.pose_trace[iter * 6 + k] = s.pose.T[k];
+    }
+    if (lane < 27) s.jtj[iter * 27 + lane] = (float)sums[lane];
+    if (nsel >= 50) {                                                            // :1210 (uniform)
+        // column `lane` of AtA (lanes 0..5), AtB on lane 6
+        float c[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int r = min(i, min(lane, 5)), cc = max(i, min(lane, 5));
+            const int k = r * 6 - (r * (r - 1)) / 2 + (cc - r);
+            c[i] = lane == 6 ? (float)sums[21 + i] : (float)sums[k];
+        }
+        float ac[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) ac[i] = c[i];
+        float X[6];
+        if (!solve6_qr_wave(c, lane, X)) {
+#pragma unroll
+            for (int r = 0; r < 6; r++) X[r] = 0.f;
+        }
+        int degenerate = iter == 0 ? 0 : s.degenerate;
+        float mp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                              // column `lane` of matP; the local matP shadows the member: zero after iteration 0
+        if (iter == 0) {
+            // isDegenerate <=> an eigenvalue of AtA below 100 (:1262-1291).  A factorisation of AtA - sigma I settles the
+            // common case: with every eigenvalue above 100 + 1e-4 trace (the Jacobi iteration's own error is two orders
+            // below that margin) nothing of cv::eigen's output is used, and the iteration does not run at all.
+            double tr = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) tr += fabs((double)(float)sums[r * 6 - (r * (r - 1)) / 2]);
+            if (!all_eig_above(sums, 100.0 + 1e-4 * tr)) {
+                float vc[6], W[6];
+                eig6_wave(ac, vc, lane, W);
+                float v2[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) v2[i] = vc[i];
+                bool below = true;
+#pragma unroll
+                for (int i = 5; i >= 0; i--) {
+                    below = below && (W[i] < 100.f);
+                    if (below) { v2[i] = 0.f; degenerate = 1; }
+                }
+                // matP = matV.inv() * matV2; V is orthogonal, inv(V) = V^T: matP[r][lane] = sum_k V[k][r] V2[k][lane]
+#pragma unroll
+                for (int r = 0; r < 6; r++) { double acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) acc += (double)rdl(vc[k], r) * (double)v2[k];
+                    mp[r] = (float)acc; }
+            }
+        }
+        if (degenerate) {
+            float X2[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) X2[r] = X[r];
+#pragma unroll
+            for (int r = 0; r < 6; r++) { double acc = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) acc += (double)rdl(mp[r], k) * (double)X2[k];
+                X[r] = (float)acc; }
+        }
+        if (lane == 0) {
+            s.any_lm = 1;
+            if (iter == 0) s.degenerate = degenerate;
+            for (int r = 0; r < 6; r++) s.pose.T[r] += X[r];
+            // pow(x, 2) of the reference is the correctly rounded double square
+            const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+            const double u0 = (double)(X[3] * 100), u1 = (double)(X[4] * 100), u2 = (double)(X[5] * 100);
+            const double dR = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+            const double dT = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
+            const float deltaR = (float)dR, deltaT = (float)dT;
+            if (deltaR < 0.05 && deltaT < 0.05) {                                    // :1309
+                s.converged = 1;
+                if (!a.disable_break) s.done = 1;
+            }
+            make_pose(s.pose);
+        }
+    }
+    if (last && lane == 0) icp_finish_body(a);
+}
+
+constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup (64: the residual phase fills its wavefront)
+static_assert(ICP_QPB == 64, "one lane of the first wavefront per feature");
+constexpr int ICP_ROW = 29;                       // doubles per feature row in LDS (28 used): 58-dword stride, conflict-free b64 accesses
+
+// round-to-nearest-even of |x| < 2^51 to an integer with one f64 add (as in lvi_voxel.hip)
+__device__ __forceinline__ long long d2ll_rn_small_icp(double x)
+{
+    const double M = 6755399441055744.0;                            // 2^52 + 2^51
+    return __double_as_longlong(x + M) - __double_as_longlong(M);
+}
+// exact fixed point of one partial sum: v = coarse 2^-16 + fine 2^-60, |v| < 2^45 (beyond: saturated)
+__device__ __forceinline__ void fx_split(double v, long long& coarse, long long& fine)
+{
+    v = fmin(fmax(v, -3.5184372088832e13), 3.5184372088832e13);                 // +-2^45
+    const double c = rint(ldexp(v, 16));
+    coarse = (long long)c;
+    fine = d2ll_rn_small_icp(ldexp(v - ldexp(c, -16), 60));                      // |v - c 2^-16| <= 2^-17: the product is below 2^44
+}
+
+// One launch = one Gauss-Newton iteration of every scan of the batch (blockIdx.z): residuals, rows, normal equations, solve,
+// pose update, convergence test, and — in the last launch — transformUpdate and the pose record.  A workgroup owns 64 features:
+//   0  first wavefront, one lane per feature: the feature's record (its five neighbours with their coordinates, where it stood
+//      at its last search, its fit) arrives in ONE round of coalesced loads; the skip test of the 5-NN search; the features
+//      that search are listed
+//   A  G lanes per LISTED feature, packed to the front of the workgroup: 5-NN; a result that differs from the record fetches
+//      the new neighbours' coordinates
+//   B  first wavefront, one lane per feature: line / plane fit when the five or their order changed (else the stored fit),
+//      evaluation at the current pose, Gauss-Newton row and its 27 products in f64 into LDS
+//   C  the 64 rows are added up in a fixed shape and the 28 sums go into the launch's exact fixed-point accumulators
+//      (integer adds commute: the totals do not depend on arrival order, on the lanes per feature or on the XCD placement);
+//      the workgroup that arrives last takes the totals and runs the 6 x 6 end of the iteration.
+template <int G, int KB>
+__global__ __launch_bounds__(64 * G) void icp_gn_kernel(Batch<IcpArgs> B_, int iter, int last)
+{
+    const IcpArgs& a = B_.a[blockIdx.z];
+    IcpState& st = *a.st;
+    // everything the prologue needs is requested before the first value is tested (one round trip instead of four in a row)
+    const int done = st.done;
+    const int nC = a.nq[0], nS = a.nq[1];
+    const float poseA = threadIdx.x < 12 ? st.pose.A[threadIdx.x] : 0.f, poseT = threadIdx.x < 6 ? st.pose.trig[threadIdx.x] : 0.f;
+    bool skip = done != 0;
+    if (!skip && iter == 0 && !(a.have_map && nC > a.edgeMin && nS > a.surfMin && nC + nS > 0)) {   // :1317, :1320 (the same in every workgroup)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st.done = 1; st.status = a.have_map ? LVI_TOO_FEW_FEATURES : LVI_NO_MAP; }
+        skip = true;
+    }
+    if (skip) {                                       // the loop is over (or never started): the last launch still finishes the scan
+        if (last && blockIdx.x == 0 && threadIdx.x == 0) icp_finish_body(a);
+        return;
+    }
+    // XCD-aware placement (speed only): workgroups b and b + 8 share an XCD and its L2, so XCD k takes a CONTIGUOUS eighth of the
+    // features — they come in voxel order, a spatial slab — and its L2 fetches that slab's part of the index and the map instead
+    // of all of it
+    const int Q = nC + nS;
+    const int nb = (Q + ICP_QPB - 1) / ICP_QPB;
+    const int per_xcd = (nb + 7) / 8;
+    const int wg = a.xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if ((a.xcd_map && (int)(blockIdx.x >> 3) >= per_xcd) || wg >= nb) return;
+    const bool stamp = (wg == Q / ICP_QPB / 2 && threadIdx.x == 0);               // a surf workgroup in the middle
+    long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
+    __shared__ float sA[12], sT[6];
+    __shared__ double srow[ICP_QPB * ICP_ROW];
+    __shared__ double spart[4][28];
+    __shared__ double ssum[28];
+    __shared__ float spt[5][3][ICP_QPB];            // the five neighbours' coordinates, in the record's order
+    __shared__ float sd[5][ICP_QPB];                // squared distances, ascending
+    __shared__ int si[5][ICP_QPB];                  // their map indices
+    __shared__ int sidr[5][ICP_QPB];                // the record's indices (phase A compares its result with them)
+    __shared__ float sori[4][ICP_QPB];
+    __shared__ float sf1[4][ICP_QPB], sf2[4][ICP_QPB];
+    __shared__ unsigned sperm[ICP_QPB];             // position in the record of the j-th nearest (3 bits each)
+    __shared__ unsigned char sfok[ICP_QPB], srefit[ICP_QPB];
+    __shared__ float sr2[ICP_QPB];                  // search radius (squared) of the features that search, in list order
+    __shared__ unsigned char slist[ICP_QPB];        // the features (workgroup-local) that search in this iteration
+    __shared__ int snsearch, slast;
+    if (threadIdx.x < 12) sA[threadIdx.x] = poseA;
+    if (threadIdx.x < 6) sT[threadIdx.x] = poseT;
+    __syncthreads();
+    const bool use_prev = a.nn_prev != nullptr && iter > 0;
+    const int cap = a.cap;
+    // Phase 0, first wavefront, one lane per feature.  From the second iteration on a feature knows its previous five
+    // neighbours; their distances under the new pose bound the fifth-nearest distance (five map points lie inside that ball),
+    // and the search either shrinks to that ball or is not needed at all: the feature's last search left a lower bound LB on
+    // the distance from where it stood THEN (ref) to every map point outside its five, so every such point is at least
+    // LB - |sel - ref| away now; if that exceeds the farthest of the five (with 2e-4 m of room for the f32 rounding of the
+    // distances, 1e-6 relative), the five are still the five nearest, no outsider can even tie, and their (distance, index)
+    // order is recomputed here with the search's own expression: the same Knn5, bit for bit, without a search.
+    if (threadIdx.x < ICP_QPB) {
+        const int ql = threadIdx.x;
+        const int t = wg * ICP_QPB + ql;
+        const bool active = t < Q;
+        const int tc = active ? t : Q - 1;
+        const lvi_pt* qp = tc < nC ? a.q[0] + tc : a.q[1] + (tc - nC);
+        const lvi_pt ori = *qp;
+        int id[5] = {-1, -1, -1, -1, -1};
+        float4 pp[5];
+        float4 ref = make_float4(0.f, 0.f, 0.f, 0.f), f1 = ref, f2 = ref;
+        unsigned fok = 0u;
+#pragma unroll
+        for (int j = 0; j < 5; j++) pp[j] = ref;
+        if (use_prev) {                                     // uniform: one round of loads, all in flight together
+#pragma unroll
+            for (int j = 0; j < 5; j++) { id[j] = a.nn_prev[(size_t)j * cap + tc]; pp[j] = a.nn_pt[(size_t)j * cap + tc]; }
+            if (a.nn_ref) ref = a.nn_ref[tc];
+            f1 = a.fit[tc]; f2 = a.fit2[tc]; fok = a.fit_ok[tc];
+        }
+        const lvi_pt sel = to_map(sA, ori);
+        bool need = active;
+        float r2 = KNN_R2_FULL;
+        unsigned perm = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
+        KnnKeys kk;
+#pragma unroll
+        for (int j = 0; j < 5; j++) kk.k[j] = KNN_EMPTY;
+        if (active && use_prev && id[0] >= 0) {
+            float b = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const float ex = sub_rn(sel.x, pp[j].x), ey = sub_rn(sel.y, pp[j].y), ez = sub_rn(sel.z, pp[j].z);
+                const float dist = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+                b = fmaxf(b, dist);
+                // (distance, index) order; the record position rides in the low three bits (indices are below 2^25)
+                knn_insert(kk, ((unsigned long long)__float_as_uint(dist) << 32) | ((unsigned)id[j] << 3) | (unsigned)j);
+            }
+            if (b < 1.0f) {
+                const float rb = sqrtf(b);
+                if (a.nn_ref) {
+                    const float dx = sel.x - ref.x, dy = sel.y - ref.y, dz = sel.z - ref.z;
+                    if (rb + sqrtf(dx * dx + dy * dy + dz * dz) + 2e-4f < sqrtf(ref.w)) need = false;
+                }
+                const float rs = rb + a.knn_slack;
+                r2 = fminf(fmaxf(b, rs * rs), KNN_R2_FULL);
+            }
+        }
+        if (!need && active) {
+            perm = 0u;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const unsigned lo = (unsigned)kk.k[j];
+                sd[j][ql] = __uint_as_float((unsigned)(kk.k[j] >> 32)); si[j][ql] = (int)(lo >> 3);
+                perm |= (lo & 7u) << (3 * j);
+            }
+            srefit[ql] = (perm != (0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12)) || fok == 0u) ? 1 : 0;
+        }
+        if (!active) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) { sd[j][ql] = INFINITY; si[j][ql] = -1; }
+            srefit[ql] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++) { spt[j][0][ql] = pp[j].x; spt[j][1][ql] = pp[j].y; spt[j][2][ql] = pp[j].z; sidr[j][ql] = id[j]; }
+        sori[0][ql] = ori.x; sori[1][ql] = ori.y; sori[2][ql] = ori.z; sori[3][ql] = ori.intensity;
+        sf1[0][ql] = f1.x; sf1[1][ql] = f1.y; sf1[2][ql] = f1.z; sf1[3][ql] = f1.w;
+        sf2[0][ql] = f2.x; sf2[1][ql] = f2.y; sf2[2][ql] = f2.z; sf2[3][ql] = f2.w;
+        sperm[ql] = perm; sfok[ql] = (unsigned char)fok;
+        const unsigned long long mk = __ballot(need);
+        if (need) { const int pos = __popcll(mk & ((1ull << ql) - 1ull)); slist[pos] = (unsigned char)ql; sr2[pos] = r2; }
+        if (ql == 0) snsearch = __popcll(mk);
+    }
+    LVI_STAMP(0);
+    __syncthreads();
+    // Phase A: G lanes per SEARCHING feature, packed to the front of the workgroup (wavefronts beyond the list have nothing to do)
+    {
+        const int gi = threadIdx.x / G, sub = threadIdx.x % G;
+        long long tk[6] = {0, 0, 0, 0, 0, 0};
+        float r2 = KNN_R2_FULL;
+        if (gi < snsearch) {
+            const int ql = slist[gi];
+            const int t = wg * ICP_QPB + ql;
+            const int w = t < nC ? 0 : 1;
+            lvi_pt ori; ori.x = sori[0][ql]; ori.y = sori[1][ql]; ori.z = sori[2][ql]; ori.intensity = 0.f;
+            const lvi_pt sel = to_map(sA, ori);
+            r2 = sr2[gi];
+            Knn5 r;
+            float lb2 = 0.f;
+            knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
+            if (sub == 0) {
+                const bool five = r.d[4] < 1.0f;
+                // the same five in the same order as the record (a search usually confirms them): its coordinates and its fit stand
+                bool same = five && use_prev && sfok[ql] != 0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) same = same && r.i[j] == sidr[j][ql];
+                if (!same) {
+                    const lvi_pt* __restrict__ map = a.mapds[w];
+                    lvi_pt nbp[5];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) nbp[j] = map[five ? r.i[j] : 0];           // unconditional: the five loads travel together
+#pragma unroll
+                    for (int j = 0; j < 5; j++) { spt[j][0][ql] = nbp[j].x; spt[j][1][ql] = nbp[j].y; spt[j][2][ql] = nbp[j].z; }
+                }
+#pragma unroll
+                for (int j = 0; j < 5; j++) { sd[j][ql] = r.d[j]; si[j][ql] = r.i[j]; }
+                sperm[ql] = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
+                srefit[ql] = same ? 0 : 1;
+                if (a.nn_ref) a.nn_ref[t] = make_float4(sel.x, sel.y, sel.z, five ? lb2 : 0.f);
+            }
+        }
+        LVI_STAMP(1);
+        if (stamp) { cyc[6] = tk[1] - tk[0]; cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; a.cyc[13] = tk[5]; a.cyc[14] = r2 < KNN_R2_FULL ? 1 : 0; }
+        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&a.cyc[15], (unsigned long long)snsearch);      // searches of this scan match, all iterations
+    }
+    __syncthreads();
+    // Phase B, first wavefront, one lane per feature
+    if (threadIdx.x < ICP_QPB) {
+        const int ql = threadIdx.x;
+        const int t = wg * ICP_QPB + ql;
+        double* row = srow + ql * ICP_ROW;
+        bool ok = false;
+        float rA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rB = 0.f;
+        if (t < Q) {
+            const bool isC = t < nC;
+            lvi_pt ori; ori.x = sori[0][ql]; ori.y = sori[1][ql]; ori.z = sori[2][ql]; ori.intensity = sori[3][ql];
+            const lvi_pt sel = to_map(sA, ori);
+            const bool five = sd[4][ql] < 1.0f;                                    // :1025, :1121
+            const bool refit = srefit[ql] != 0;
+            const unsigned perm = sperm[ql];
+            lvi_pt nb[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) { const int m = (perm >> (3 * j)) & 7u; nb[j].x = spt[m][0][ql]; nb[j].y = spt[m][1][ql]; nb[j].z = spt[m][2][ql]; nb[j].intensity = 0.f; }
+            float4 f1 = make_float4(sf1[0][ql], sf1[1][ql], sf1[2][ql], sf1[3][ql]), f2 = make_float4(sf2[0][ql], sf2[1][ql], sf2[2][ql], sf2[3][ql]);
+            unsigned fok = sfok[ql];
+            if (refit) {
+                if (five) {
+                    bool valid;
+                    if (isC) valid = corner_fit(nb, f1, f2); else valid = surf_fit(nb, f1);
+                    fok = valid ? 1u : 2u;
+                } else fok = 0u;
+                if (a.nn_prev) {                            // the record follows the fit: neighbours in the fit's order, their coordinates, the fit
+#pragma unroll
+                    for (int j = 0; j < 5; j++) {
+                        a.nn_prev[(size_t)j * cap + t] = five ? si[j][ql] : -1;
+                        a.nn_pt[(size_t)j * cap + t] = make_float4(nb[j].x, nb[j].y, nb[j].z, 0.f);
+                    }
+                    a.fit[t] = f1; a.fit_ok[t] = (unsigned char)fok;
+                    if (isC) a.fit2[t] = f2;
+                }
+            }
+            lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
+            if (five && fok == 1u) ok = isC ? corner_eval(f1, f2, sel, cf) : surf_eval(f1, ori, sel, cf);
+            if (ok) lm_row(sT, ori, cf, rA, rB);
+        }
+        {
+            int k = 0;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+                for (int c = rr; c < 6; c++) row[k++] = ok ? (double)rA[rr] * (double)rA[c] : 0.0;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++) row[21 + rr] = ok ? (double)rA[rr] * (double)rB : 0.0;
+            row[27] = ok ? 1.0 : 0.0;
+        }
+    }
+    LVI_STAMP(3);
+    __syncthreads();
+    // Phase C: 4 x 16 rows, then the four group sums, in that fixed shape; the sums join the launch's totals as exact integers
+    if (threadIdx.x < 128) {
+        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+        if (k < 28) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) v += srow[(g * 16 + q) * ICP_ROW + k];
+            spart[g][k] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_QPB) {                       // the first wavefront: adds, drain, ticket
+        if (threadIdx.x < 28) {
+            const double v = ((spart[0][threadIdx.x] + spart[1][threadIdx.x]) + spart[2][threadIdx.x]) + spart[3][threadIdx.x];
+            long long co, fi;
+            fx_split(v, co, fi);
+            if (co) atomicAdd(&a.acc[threadIdx.x], (unsigned long long)co);
+            if (fi) atomicAdd(&a.acc[28 + threadIdx.x], (unsigned long long)fi);
+        }
+        // the adds of this wavefront are performed at the memory side before its ticket is drawn (vmcnt counts an atomic
+        // until its acknowledgement): the workgroup whose ticket is the last one finds every workgroup's adds in the totals
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) slast = (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nb - 1)) ? 1 : 0;
+    }
+    LVI_STAMP(4);
+    if (stamp) { cyc[5] = clock64() - t_first; for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q]; }
+#undef LVI_STAMP
+    __syncthreads();
+    if (!slast || threadIdx.x >= 64) return;
+    {
+        const long long tq0 = clock64();
+        // the totals, taken with an exchange (executed where the adds were executed; leaves the accumulators zero for the next launch)
+        if (threadIdx.x < 56) {
+            const unsigned long long v = atomicExch(&a.acc[threadIdx.x], 0ull);
+            srow[threadIdx.x] = ldexp((double)(long long)v, threadIdx.x < 28 ? -16 : -60);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();      // one wavefront: its LDS operations complete in order
+        if (threadIdx.x < 28) ssum[threadIdx.x] = srow[threadIdx.x] + srow[28 + threadIdx.x];
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
+        const long long tq1 = clock64();
+        icp_solve_tail(a, iter, last, ssum);
+        if (a.cyc && iter == 1 && threadIdx.x == 0) { const long long tq2 = clock64(); a.cyc[8] = tq1 - tq0; a.cyc[9] = tq2 - tq1; a.cyc[12] = tq2 - tq0; }
+    }
+}
+
 
 __global__ __launch_bounds__(256) void transform_kernel(const lvi_pt* in, int n, IcpPose pose, lvi_pt* out)
 {
@@ -1069,7 +1259,7 @@ __global__ __launch_bounds__(256) void transform_dev_pose_kernel(const lvi_pt* i
     out[i] = to_map(pose->A, in[i]);
 }
 
-__global__ __launch_bounds__(ICP_BLOCK) void residual_debug_kernel(IcpArgs a, int which, const IcpPose* pose)
+__global__ __launch_bounds__(ICP_BLOCK) void residual_debug_kernel(IcpArgs a, int which, const IcpPose* pose, lvi_pt* coeff, uint8_t* flag)
 {
     const int n = a.nq[which];
     const int ql = threadIdx.x / KNN_G, sub = threadIdx.x % KNN_G;
@@ -1084,8 +1274,8 @@ __global__ __launch_bounds__(ICP_BLOCK) void residual_debug_kernel(IcpArgs a, in
     if (active && sub == 0) {
         lvi_pt cf = {0.f, 0.f, 0.f, 0.f};
         const bool ok = which == 0 ? corner_residual(a, sel, r, cf) : surf_residual(a, ori, sel, r, cf);
-        a.flag[t] = ok ? 1 : 0;
-        a.coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
+        flag[t] = ok ? 1 : 0;
+        coeff[t] = ok ? cf : lvi_pt{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -1102,7 +1292,8 @@ IcpArgs icp_args(LidarDev& d)
     a.q[0] = d.cornerDS; a.q[1] = d.surfDS; a.nq = d.voxScan.d_nout;
     for (int w = 0; w < 2; w++) { a.meta[w] = d.grid[w].meta; a.cell_start[w] = d.grid[w].cell_start; a.sorted[w] = d.grid[w].sorted; }
     a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
-    a.coeff = d.coeff; a.flag = d.flag; a.partial = d.icpPartial; a.cyc = d.d_icp_cycles; a.d_status = d.d_status; a.nn_prev = d.knn_bound ? d.nnPrev : nullptr;
+    a.cyc = d.d_icp_cycles; a.d_status = d.d_status; a.nn_prev = d.knn_bound ? d.nnPrev : nullptr;
+    a.cap = d.ext_cap; a.nn_pt = d.nnPt; a.fit = d.fitA; a.fit2 = d.fitB; a.fit_ok = d.fitOk; a.acc = d.icpAcc; a.ticket = d.icpTicket;
     a.nn_ref = (d.knn_bound && d.knn_skip) ? d.nnRef : nullptr; a.knn_slack = d.knn_slack;
     { static const bool no_map = getenv("LVI_ICP_NO_XCD_MAP") != nullptr; a.xcd_map = no_map ? 0 : 1; }
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
@@ -1324,6 +1515,7 @@ void set_pose_init(const Slots& sl, const float* p, bool clear_status)
         B.a[z].dst = sl[z].d_pose_init;
         for (int k = 0; k < 6; k++) B.a[z].t[k] = p[6 * z + k];
         B.a[z].d_status = clear_status ? sl[z].d_status : nullptr;
+        B.a[z].st = sl[z].icp; B.a[z].cyc = sl[z].d_icp_cycles; B.a[z].acc = sl[z].icpAcc; B.a[z].ticket = sl[z].icpTicket;
     }
     for (int z = sl.n; z < MAX_BATCH; z++) B.a[z] = B.a[0];
     const Ctx& cx = sl.first().ctx;
@@ -1344,7 +1536,6 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
         a.imu_roll = imu ? imu->imu_roll_init : 0.f;
         a.imu_pitch = imu ? imu->imu_pitch_init : 0.f;
         a.d_record = d_records ? (void*)((char*)d_records + sizeof(lvi_pose_record) * (size_t)z) : nullptr;
-        a.pose_init = sl[z].d_pose_init;
         a.have_map = sl[z].have_map ? 1 : 0;
         B.a[z] = a;
         Q += 0.25 * sl[z].n_raw;           // nominal query count for byte accounting only
@@ -1353,19 +1544,19 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
     const IcpArgs& a = B.a[0];
     const unsigned S = (unsigned)sl.n;
     const Ctx& cx = d.ctx;
-    LVI_LAUNCH(cx, "icp_init", 0, hipLaunchKernelGGL(icp_init_kernel, dim3(1, 1, S), dim3(1), 0, cx.stream, B));
     for (int it = 0; it < a.max_iters; it++) {
         // (the grid covers ext_cap features; the ~1 200 workgroups beyond the actual count exit at once — measured: launching
         // exactly the occupied 360 instead changes nothing)
-        // iteration 0 searches the unit ball with 8 lanes per feature; later iterations search the (much smaller) ball of the
-        // previous neighbours, where the per-lane fixed cost dominates: fewer lanes per feature (d.icp_g1)
+        // iteration 0 searches the unit ball; later iterations search the (much smaller) ball of the previous neighbours, where
+        // the per-lane fixed cost dominates: fewer lanes per feature (d.icp_g1).  The solve, the pose update and — in the last
+        // launch — transformUpdate run in the workgroup that arrives last: ONE launch per Gauss-Newton iteration.
         const int G1 = it == 0 ? d.icp_g0 : d.icp_g1;
+        const int lastf = it == a.max_iters - 1 ? 1 : 0;
         const dim3 rg((d.nblk_icp + 7) & ~7, 1, S);               // a multiple of 8: the kernel deals its workgroups to the XCDs in contiguous ranges
-        if (G1 == 8) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<8, 8>), rg, dim3(512), 0, cx.stream, B));
-        else if (G1 == 4) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<4, 4>), rg, dim3(256), 0, cx.stream, B));
-        else if (G1 == 2) LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<2, 4>), rg, dim3(128), 0, cx.stream, B));
-        else LVI_LAUNCH(cx, "icp_residual", 128.0 * Q, hipLaunchKernelGGL((icp_residual_kernel<8, 4>), rg, dim3(512), 0, cx.stream, B));
-        LVI_LAUNCH(cx, "icp_solve", 0, hipLaunchKernelGGL(icp_solve_kernel, dim3(1, 1, S), dim3(SOLVE_THREADS), 0, cx.stream, B, it, it == a.max_iters - 1 ? 1 : 0));
+        if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<8, 8>), rg, dim3(512), 0, cx.stream, B, it, lastf));
+        else if (G1 == 4) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<4, 4>), rg, dim3(256), 0, cx.stream, B, it, lastf));
+        else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<2, 4>), rg, dim3(128), 0, cx.stream, B, it, lastf));
+        else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<8, 4>), rg, dim3(512), 0, cx.stream, B, it, lastf));
     }
     if (a.max_iters <= 0) LVI_LAUNCH(cx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1, 1, S), dim3(1), 0, cx.stream, B));
 }
@@ -1384,7 +1575,7 @@ void debug_residuals(LidarDev& d, int which, const float pose[6])
     join_map(d);
     IcpArgs a = icp_args(d);
     hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->pose, pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]);
-    hipLaunchKernelGGL(residual_debug_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a, which, &d.icp->pose);
+    hipLaunchKernelGGL(residual_debug_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a, which, &d.icp->pose, d.coeff, d.flag);
     LVI_HIP(hipGetLastError());
 }
 

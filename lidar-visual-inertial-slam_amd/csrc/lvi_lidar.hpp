@@ -103,9 +103,13 @@ struct LidarDev {
     unsigned* genKeysDbg = nullptr;
     // ---- icp
     IcpState* icp = nullptr;
-    double* icpPartial = nullptr;                          // [nblk_icp][28]
-    lvi_pt* coeff = nullptr; uint8_t* flag = nullptr;      // [ext_cap] corner queries first, then surf
-    int* nnPrev = nullptr;                                 // [ext_cap][5] neighbours found by the previous GN iteration
+    unsigned long long* icpAcc = nullptr;                  // [56] exact fixed-point totals of the 28 sums of one GN launch (coarse, fine), zero between launches
+    unsigned* icpTicket = nullptr;                         // [1] arrival ticket of the GN launch, zero between launches
+    lvi_pt* coeff = nullptr; uint8_t* flag = nullptr;      // [ext_cap] lvi_debug_residuals only
+    int* nnPrev = nullptr;                                 // [5][ext_cap] the five neighbours of the feature's last search, in its fit's order
+    float4* nnPt = nullptr;                                // [5][ext_cap] their coordinates
+    float4 *fitA = nullptr, *fitB = nullptr;               // [ext_cap] the line / plane fitted to them
+    unsigned char* fitOk = nullptr;                        // [ext_cap]
     int icp_g0 = 4;                                        // lanes per feature in GN iteration 0 (whole unit ball; LVI_ICP_G0; measured with 16 scans in flight: 8 lanes 5 030, 4 lanes 5 245 scans/s)
     int icp_g1 = 4;                                        // lanes per feature in GN iterations >= 1 (LVI_ICP_G1 = 8 | 4 | 2 | 84 (8 lanes, batches of 4))
     float4* nnRef = nullptr;                               // [ext_cap] position at the feature's last search + squared lower bound on the distance to the map points outside its five

@@ -930,10 +930,13 @@ void layout(AR& ar, LidarDev& d)
     d.d_kfSeg = ar.template alloc<LidarDev::KfSeg>((size_t)std::max(d.kf_seg_cap, 1));
     d.icp = ar.template alloc<IcpState>(1);
     d.d_pose_init = ar.template alloc<float>(8);
-    d.icpPartial = ar.template alloc<double>((size_t)d.nblk_icp * 28);
+    d.icpAcc = ar.template alloc<unsigned long long>(64); d.icpTicket = ar.template alloc<unsigned>(4);
     d.coeff = ar.template alloc<lvi_pt>(d.ext_cap); d.flag = ar.template alloc<uint8_t>(d.ext_cap);
     d.nnPrev = ar.template alloc<int>((size_t)d.ext_cap * 5);
     d.nnRef = ar.template alloc<float4>((size_t)d.ext_cap);
+    d.nnPt = ar.template alloc<float4>((size_t)d.ext_cap * 5);
+    d.fitA = ar.template alloc<float4>((size_t)d.ext_cap); d.fitB = ar.template alloc<float4>((size_t)d.ext_cap);
+    d.fitOk = ar.template alloc<unsigned char>((size_t)d.ext_cap);
 }
 
 FeatArgs feat_args(LidarDev& d)
