@@ -490,10 +490,11 @@ struct IcpArgs {
     unsigned char* fit_ok;                        // [cap] 0: no fit stored; 1: stored, geometric gate passed; 2: stored, gate failed
     float knn_slack;                              // metres added to the radius of a bounded search (room for later iterations to skip theirs)
     int xcd_map;                                  // residual workgroups are dealt to the XCDs in contiguous feature ranges (LVI_ICP_NO_XCD_MAP=1: in launch order)
-    // normal equations: 28 columns x {coarse, fine} exact fixed-point accumulators + the arrival ticket of the launch
-    unsigned long long* acc;                      // [56], zero between launches (the last arriver takes them with an exchange)
-    unsigned* ticket;                             // [1], zero between launches
+    // normal equations: 28 columns x {coarse, fine} exact fixed-point accumulators, ICP_SHARDS shards (workgroup & 7), three
+    // buffers in rotation: launch i adds into buffer i % 3, reads the totals of launch i - 1 from (i - 1) % 3 and zeroes (i + 1) % 3
+    unsigned long long* acc;                      // [3][ICP_SHARDS][56]
 };
+constexpr int ICP_SHARDS = 8;
 
 __device__ __forceinline__ lvi_pt to_map(const float A[12], const lvi_pt& p)       // pointAssociateToMap :339-345
 {
@@ -634,21 +635,22 @@ __device__ void make_pose(IcpPose& p)
 // The initial guess of a scan match and the reset of its Gauss-Newton state (what scan2MapOptimization starts from, :1315-1322):
 // one thread per batch slot.  The feature-count gates (:1317, :1320) are evaluated by the first Gauss-Newton launch, where the
 // counts of the scan's grids exist.
-struct PoseInitArgs { float* dst; float t[6]; int* d_status; IcpState* st; long long* cyc; unsigned long long* acc; unsigned* ticket; };
-__global__ void set_pose_init_kernel(Batch<PoseInitArgs> B_)
+struct PoseInitArgs { float* dst; float t[6]; int* d_status; IcpState* st; long long* cyc; unsigned long long* acc; };
+__global__ __launch_bounds__(64) void set_pose_init_kernel(Batch<PoseInitArgs> B_)
 {
     const PoseInitArgs& a = B_.a[blockIdx.z];
+    for (int k = threadIdx.x; k < ICP_SHARDS * 56; k += 64) a.acc[k] = 0ull;      // buffer 0: the first launch adds into it
+    if (threadIdx.x != 0) return;
 #pragma unroll
     for (int k = 0; k < 6; k++) a.dst[k] = a.t[k];
     if (a.d_status) a.d_status[0] = 0;            // scan-side device status word of a batch slot (single scans: cleared by the upload)
     IcpState& s = *a.st;
-    for (int k = 0; k < 6; k++) s.pose.T[k] = a.t[k];
-    make_pose(s.pose);
+    for (int k = 0; k < 6; k++) s.pose[0].T[k] = a.t[k];
+    make_pose(s.pose[0]);
+    s.cur = 0;
     s.done = 0; s.converged = 0; s.degenerate = 0; s.iters = 0; s.any_lm = 0; s.status = LVI_OK;
     a.cyc[15] = 0;                                 // searches counted by the Gauss-Newton kernel (debug read-out)
     for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) s.n_sel[i] = 0;
-    for (int k = 0; k < 56; k++) a.acc[k] = 0ull;  // (zero already unless a launch sequence was cut short)
-    *a.ticket = 0u;
 }
 
 // tf2 pieces of transformUpdate (doubles)
@@ -686,7 +688,7 @@ __device__ void q_to_rpy(const Quatd& q, double& roll, double& pitch, double& ya
 __device__ void icp_finish_body(const IcpArgs& a)
 {
     IcpState& s = *a.st;
-    float* T = s.pose.T;
+    float* T = s.pose[s.cur & 1].T;
     const bool ran = (s.status == LVI_OK);
     if (ran) {
         for (int k = 0; k < 6; k++) s.pose_trace[s.iters * 6 + k] = T[k];
@@ -710,15 +712,6 @@ __device__ void icp_finish_body(const IcpArgs& a)
     s.record.status = s.status; s.record.iters = s.iters;
     if (a.d_record) *reinterpret_cast<lvi_pose_record*>(a.d_record) = s.record;
 }
-__global__ void icp_finish_kernel(Batch<IcpArgs> B_)       // only launched when icp_max_iters == 0
-{
-    const IcpArgs& a = B_.a[blockIdx.z];
-    IcpState& s = *a.st;
-    if (!a.have_map) s.status = LVI_NO_MAP;                                                           // :1317
-    else if (!(a.nq[0] > a.edgeMin && a.nq[1] > a.surfMin)) s.status = LVI_TOO_FEW_FEATURES;          // :1320
-    icp_finish_body(a);
-}
-
 // ------------------------------------------------------------------------------------------- the 6 x 6 end of an iteration, on ONE wavefront
 // Lane j < 6 holds column j of the symmetric 6 x 6 matrix, lane 6 the right-hand side; values that every lane needs are read
 // across with v_readlane (compile-time lane and register): a few dozen registers instead of the ~250 of the all-in-one-lane form,
@@ -847,20 +840,36 @@ __device__ __forceinline__ void eig6_wave(float ac[6], float vc[6], int lane, fl
     }
 }
 
-// combineOptimizationCoeffs + LMOptimization past the row products (:1169-1313), transformUpdate when this was the last
-// iteration: the first wavefront of the workgroup whose ticket was the last of the launch.  sums[28] (LDS): the 21 + 6 sums
-// of AtA / AtB and the number of selected rows.
-__device__ __forceinline__ void icp_solve_tail(const IcpArgs& a, int iter, int last, const double* sums)
+// pcl::getTransformation + the trigonometric terms of LMOptimization from T (every lane the same T): three lanes take one
+// angle each (sincos in double, as make_pose), every lane assembles the matrix from their results
+__device__ __forceinline__ void make_pose_wave(IcpPose& p, int lane)
+{
+    double sn, cs;
+    const float ang = lane == 0 ? p.T[0] : (lane == 1 ? p.T[1] : p.T[2]);
+    sincos((double)ang, &sn, &cs);                     // (every lane: lanes >= 3 repeat lane 2's angle)
+    const float fs = (float)sn, fc = (float)cs;
+    const float F = rdl(fs, 0), E = rdl(fc, 0), D = rdl(fs, 1), C = rdl(fc, 1), B = rdl(fs, 2), A = rdl(fc, 2), DE = D * E, DF = D * F;
+    p.A[0] = A * C; p.A[1] = A * DF - B * E; p.A[2] = B * F + A * DE; p.A[3] = p.T[3];
+    p.A[4] = B * C; p.A[5] = A * E + B * DF; p.A[6] = B * DE - A * F; p.A[7] = p.T[4];
+    p.A[8] = -D;    p.A[9] = C * F;          p.A[10] = C * E;         p.A[11] = p.T[5];
+    p.trig[0] = D; p.trig[1] = C; p.trig[2] = B; p.trig[3] = A; p.trig[4] = F; p.trig[5] = E;
+}
+
+// The end of Gauss-Newton iteration `iter` — combineOptimizationCoeffs + LMOptimization past the row products (:1169-1313) —
+// on one wavefront: sums[28] (LDS) = the 21 + 6 sums of AtA / AtB and the number of selected rows, P.T = the pose the rows were
+// made with.  On return P is the pose of iteration iter + 1; the return value says whether the loop is over (converged and
+// break enabled).  EVERY workgroup of the next launch runs this on the same integers, so every workgroup holds the same pose
+// without any exchange inside a launch; the one with `writer` set also keeps the scan's state in global memory.
+__device__ __forceinline__ int icp_iter_end(const IcpArgs& a, int iter, const double* sums, int lane, bool writer, int degen_in, IcpPose& P)
 {
     IcpState& s = *a.st;
-    const int lane = threadIdx.x;                                                 // < 64
     const int nsel = (int)sums[27];
-    if (lane == 0) {
-        s.n_sel[iter] = nsel;
-        s.iters = iter + 1;
-        for (int k = 0; k < 6; k++) s.pose_trace[iter * 6 + k] = s.pose.T[k];
+    int done = 0;
+    if (writer) {
+        if (lane == 0) { s.n_sel[iter] = nsel; s.iters = iter + 1; }
+        if (lane < 6) s.pose_trace[iter * 6 + lane] = lane == 0 ? P.T[0] : lane == 1 ? P.T[1] : lane == 2 ? P.T[2] : lane == 3 ? P.T[3] : lane == 4 ? P.T[4] : P.T[5];
+        if (lane < 27) s.jtj[iter * 27 + lane] = (float)sums[lane];
     }
-    if (lane < 27) s.jtj[iter * 27 + lane] = (float)sums[lane];
     if (nsel >= 50) {                                                            // :1210 (uniform)
         // column `lane` of AtA (lanes 0..5), AtB on lane 6
         float c[6];
@@ -878,7 +887,7 @@ __device__ __forceinline__ void icp_solve_tail(const IcpArgs& a, int iter, int l
 #pragma unroll
             for (int r = 0; r < 6; r++) X[r] = 0.f;
         }
-        int degenerate = iter == 0 ? 0 : s.degenerate;
+        int degenerate = iter == 0 ? 0 : degen_in;                                // (written by the launch that ended iteration 0, read at this launch's entry)
         float mp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                              // column `lane` of matP; the local matP shadows the member: zero after iteration 0
         if (iter == 0) {
             // isDegenerate <=> an eigenvalue of AtA below 100 (:1262-1291).  A factorisation of AtA - sigma I settles the
@@ -917,29 +926,54 @@ __device__ __forceinline__ void icp_solve_tail(const IcpArgs& a, int iter, int l
                 for (int k = 0; k < 6; k++) acc += (double)rdl(mp[r], k) * (double)X2[k];
                 X[r] = (float)acc; }
         }
-        if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) P.T[r] += X[r];
+        // pow(x, 2) of the reference is the correctly rounded double square
+        const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+        const double u0 = (double)(X[3] * 100), u1 = (double)(X[4] * 100), u2 = (double)(X[5] * 100);
+        const double dR = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+        const double dT = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
+        const float deltaR = (float)dR, deltaT = (float)dT;
+        const bool conv = deltaR < 0.05 && deltaT < 0.05;                         // :1309
+        if (conv && !a.disable_break) done = 1;
+        if (writer && lane == 0) {
             s.any_lm = 1;
             if (iter == 0) s.degenerate = degenerate;
-            for (int r = 0; r < 6; r++) s.pose.T[r] += X[r];
-            // pow(x, 2) of the reference is the correctly rounded double square
-            const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
-            const double u0 = (double)(X[3] * 100), u1 = (double)(X[4] * 100), u2 = (double)(X[5] * 100);
-            const double dR = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-            const double dT = sqrt(u0 * u0 + u1 * u1 + u2 * u2);
-            const float deltaR = (float)dR, deltaT = (float)dT;
-            if (deltaR < 0.05 && deltaT < 0.05) {                                    // :1309
-                s.converged = 1;
-                if (!a.disable_break) s.done = 1;
-            }
-            make_pose(s.pose);
+            if (conv) { s.converged = 1; if (!a.disable_break) s.done = 1; }
         }
     }
-    if (last && lane == 0) icp_finish_body(a);
+    make_pose_wave(P, lane);
+    if (writer) {
+        IcpPose& out = s.pose[(iter + 1) & 1];
+        if (lane < 6) out.T[lane] = lane == 0 ? P.T[0] : lane == 1 ? P.T[1] : lane == 2 ? P.T[2] : lane == 3 ? P.T[3] : lane == 4 ? P.T[4] : P.T[5];
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) out.A[k] = P.A[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) out.trig[k] = P.trig[k];
+            s.cur = (iter + 1) & 1;
+        }
+    }
+    return done;
 }
 
-constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup (64: the residual phase fills its wavefront)
-static_assert(ICP_QPB == 64, "one lane of the first wavefront per feature");
-constexpr int ICP_ROW = 29;                       // doubles per feature row in LDS (28 used): 58-dword stride, conflict-free b64 accesses
+// the totals of a launch: 8 shards x 56 exact integers -> sums[28] (one wavefront; the shards' loads travel together)
+__device__ __forceinline__ void icp_take_sums(const IcpArgs& a, int iter, int lane, double* sums, double* tmp)
+{
+    const unsigned long long* __restrict__ buf = a.acc + (size_t)(iter % 3) * (ICP_SHARDS * 56);
+    unsigned long long v[ICP_SHARDS];
+#pragma unroll
+    for (int h = 0; h < ICP_SHARDS; h++) v[h] = buf[h * 56 + min(lane, 55)];
+    unsigned long long tot = 0ull;
+#pragma unroll
+    for (int h = 0; h < ICP_SHARDS; h++) tot += v[h];
+    if (lane < 56) tmp[lane] = ldexp((double)(long long)tot, lane < 28 ? -16 : -60);
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();      // one wavefront: its LDS operations complete in order
+    if (lane < 28) sums[lane] = tmp[lane] + tmp[28 + lane];
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int ICP_QPB = ICP_BLOCK / KNN_G;        // features per workgroup of lvi_debug_residuals' kernel
 
 // round-to-nearest-even of |x| < 2^51 to an integer with one f64 add (as in lvi_voxel.hip)
 __device__ __forceinline__ long long d2ll_rn_small_icp(double x)
@@ -956,97 +990,137 @@ __device__ __forceinline__ void fx_split(double v, long long& coarse, long long&
     fine = d2ll_rn_small_icp(ldexp(v - ldexp(c, -16), 60));                      // |v - c 2^-16| <= 2^-17: the product is below 2^44
 }
 
-// One launch = one Gauss-Newton iteration of every scan of the batch (blockIdx.z): residuals, rows, normal equations, solve,
-// pose update, convergence test, and — in the last launch — transformUpdate and the pose record.  A workgroup owns 64 features:
-//   0  first wavefront, one lane per feature: the feature's record (its five neighbours with their coordinates, where it stood
-//      at its last search, its fit) arrives in ONE round of coalesced loads; the skip test of the 5-NN search; the features
-//      that search are listed
-//   A  G lanes per LISTED feature, packed to the front of the workgroup: 5-NN; a result that differs from the record fetches
-//      the new neighbours' coordinates
-//   B  first wavefront, one lane per feature: line / plane fit when the five or their order changed (else the stored fit),
-//      evaluation at the current pose, Gauss-Newton row and its 27 products in f64 into LDS
-//   C  the 64 rows are added up in a fixed shape and the 28 sums go into the launch's exact fixed-point accumulators
-//      (integer adds commute: the totals do not depend on arrival order, on the lanes per feature or on the XCD placement);
-//      the workgroup that arrives last takes the totals and runs the 6 x 6 end of the iteration.
-template <int G, int KB>
-__global__ __launch_bounds__(64 * G) void icp_gn_kernel(Batch<IcpArgs> B_, int iter, int last)
+// One launch = one Gauss-Newton iteration of every scan of the batch (blockIdx.z): the end of the PREVIOUS iteration (solve,
+// pose update, convergence test — from the exact totals the previous launch left), then residuals, rows and normal equations
+// of this one.  A workgroup owns QPB features (64 in iteration 0, where every feature searches the unit ball and the chip wants
+// many workgroups; 256 afterwards, where a workgroup is four wavefronts of one lane per feature and the head of the launch is
+// paid once per 256 features):
+//   H  first wavefront: totals of the previous launch -> 6 x 6 solve -> pose of this iteration (every workgroup: no exchange)
+//   0  one lane per feature: the feature's record (its five neighbours with their coordinates, where it stood at its last
+//      search, its fit) arrives in ONE round of coalesced loads, requested before H starts; the skip test of the 5-NN search; the
+//      features that search are listed
+//   A  G lanes per LISTED feature, NT / G features per round: 5-NN; a result that differs from the record fetches the new
+//      neighbours' coordinates
+//   B  one lane per feature: line / plane fit when the five or their order changed (else the stored fit), evaluation at the
+//      current pose, the Gauss-Newton row (6 + 1 floats) into LDS
+//   C  the 27 products of the rows are formed in f64 and added up in a fixed shape; the 28 sums join the launch's exact
+//      fixed-point accumulators (integer adds commute: the totals do not depend on arrival order, on the lanes per feature or
+//      on the XCD placement).  Nobody waits for the adds: the next launch reads the totals.
+template <int QPB, bool FIRST, int G, int KB>
+__global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<IcpArgs> B_, int iter)
 {
+    constexpr int NT = QPB == 64 ? 64 * G : 256;
+    static_assert(QPB == 64 || QPB == 256, "features per workgroup");
+    static_assert(!FIRST || QPB == 64, "iteration 0 (no previous iteration to end, no records to read) runs the 64-feature form");
+    static_assert(NT >= 128 && NT >= QPB, "phase C uses 128 threads; phases 0 and B one lane per feature");
     const IcpArgs& a = B_.a[blockIdx.z];
     IcpState& st = *a.st;
-    // everything the prologue needs is requested before the first value is tested (one round trip instead of four in a row)
+    // everything the head needs is requested before the first value is tested (one round trip instead of four in a row)
     const int done = st.done;
     const int nC = a.nq[0], nS = a.nq[1];
-    const float poseA = threadIdx.x < 12 ? st.pose.A[threadIdx.x] : 0.f, poseT = threadIdx.x < 6 ? st.pose.trig[threadIdx.x] : 0.f;
-    bool skip = done != 0;
-    if (!skip && iter == 0 && !(a.have_map && nC > a.edgeMin && nS > a.surfMin && nC + nS > 0)) {   // :1317, :1320 (the same in every workgroup)
+    const IcpPose& pin = st.pose[(iter + 1) & 1];   // iteration 0: buffer 0 holds the initial guess (set_pose_init); iteration i: the pose launch i - 1 worked with
+    const IcpPose& p0 = st.pose[0];
+    const float poseA = threadIdx.x < 12 ? p0.A[threadIdx.x] : 0.f, poseT = threadIdx.x < 6 ? p0.trig[threadIdx.x] : 0.f;
+    const float tin = pin.T[threadIdx.x % 6];
+    const int degen_in = st.degenerate;
+    if (done) return;                                // the loop is over (icp_final_kernel finishes the scan)
+    if (FIRST && !(a.have_map && nC > a.edgeMin && nS > a.surfMin && nC + nS > 0)) {   // :1317, :1320 (the same in every workgroup)
         if (blockIdx.x == 0 && threadIdx.x == 0) { st.done = 1; st.status = a.have_map ? LVI_TOO_FEW_FEATURES : LVI_NO_MAP; }
-        skip = true;
-    }
-    if (skip) {                                       // the loop is over (or never started): the last launch still finishes the scan
-        if (last && blockIdx.x == 0 && threadIdx.x == 0) icp_finish_body(a);
         return;
     }
     // XCD-aware placement (speed only): workgroups b and b + 8 share an XCD and its L2, so XCD k takes a CONTIGUOUS eighth of the
     // features — they come in voxel order, a spatial slab — and its L2 fetches that slab's part of the index and the map instead
     // of all of it
     const int Q = nC + nS;
-    const int nb = (Q + ICP_QPB - 1) / ICP_QPB;
+    const int nb = (Q + QPB - 1) / QPB;
     const int per_xcd = (nb + 7) / 8;
     const int wg = a.xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if ((a.xcd_map && (int)(blockIdx.x >> 3) >= per_xcd) || wg >= nb) return;
-    const bool stamp = (wg == Q / ICP_QPB / 2 && threadIdx.x == 0);               // a surf workgroup in the middle
+    const bool stamp = (wg == nb / 2 && threadIdx.x == 0);                         // a surf workgroup in the middle
     long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     __shared__ float sA[12], sT[6];
-    __shared__ double srow[ICP_QPB * ICP_ROW];
-    __shared__ double spart[4][28];
-    __shared__ double ssum[28];
-    __shared__ float spt[5][3][ICP_QPB];            // the five neighbours' coordinates, in the record's order
-    __shared__ float sd[5][ICP_QPB];                // squared distances, ascending
-    __shared__ int si[5][ICP_QPB];                  // their map indices
-    __shared__ int sidr[5][ICP_QPB];                // the record's indices (phase A compares its result with them)
-    __shared__ float sori[4][ICP_QPB];
-    __shared__ float sf1[4][ICP_QPB], sf2[4][ICP_QPB];
-    __shared__ unsigned sperm[ICP_QPB];             // position in the record of the j-th nearest (3 bits each)
-    __shared__ unsigned char sfok[ICP_QPB], srefit[ICP_QPB];
-    __shared__ float sr2[ICP_QPB];                  // search radius (squared) of the features that search, in list order
-    __shared__ unsigned char slist[ICP_QPB];        // the features (workgroup-local) that search in this iteration
-    __shared__ int snsearch, slast;
-    if (threadIdx.x < 12) sA[threadIdx.x] = poseA;
-    if (threadIdx.x < 6) sT[threadIdx.x] = poseT;
-    __syncthreads();
-    const bool use_prev = a.nn_prev != nullptr && iter > 0;
+    __shared__ __attribute__((aligned(16))) float srow[QPB][8];                  // the Gauss-Newton row of a feature: matA(i, 0..5), matB(i), selected (1 / 0)
+    __shared__ long long spi[QPB / 16][56];         // exact fixed-point images (coarse, fine) of the sums of 16 consecutive features
+    __shared__ double ssum[28], stmp[56];
+    __shared__ float spt[5][3][QPB];                // the five neighbours' coordinates, in the record's order
+    __shared__ float sd[5][QPB];                    // squared distances, ascending
+    __shared__ int si[5][QPB];                      // their map indices
+    __shared__ int sidr[5][QPB];                    // the record's indices (phase A compares its result with them)
+    __shared__ float sori[4][QPB];
+    __shared__ unsigned short sperm[QPB];           // position in the record of the j-th nearest (3 bits each)
+    __shared__ unsigned char sfok[QPB], srefit[QPB];
+    __shared__ float sr2[QPB];                      // search radius (squared) of the features that search, in list order
+    __shared__ unsigned short slist[QPB];           // the features (workgroup-local) that search in this iteration
+    __shared__ int swcnt[QPB / 64];                 // searching features per wavefront
+    __shared__ int sdone;
+    const bool use_prev = !FIRST && a.nn_prev != nullptr;
     const int cap = a.cap;
-    // Phase 0, first wavefront, one lane per feature.  From the second iteration on a feature knows its previous five
-    // neighbours; their distances under the new pose bound the fifth-nearest distance (five map points lie inside that ball),
-    // and the search either shrinks to that ball or is not needed at all: the feature's last search left a lower bound LB on
-    // the distance from where it stood THEN (ref) to every map point outside its five, so every such point is at least
-    // LB - |sel - ref| away now; if that exceeds the farthest of the five (with 2e-4 m of room for the f32 rounding of the
-    // distances, 1e-6 relative), the five are still the five nearest, no outsider can even tie, and their (distance, index)
-    // order is recomputed here with the search's own expression: the same Knn5, bit for bit, without a search.
-    if (threadIdx.x < ICP_QPB) {
-        const int ql = threadIdx.x;
-        const int t = wg * ICP_QPB + ql;
-        const bool active = t < Q;
-        const int tc = active ? t : Q - 1;
-        const lvi_pt* qp = tc < nC ? a.q[0] + tc : a.q[1] + (tc - nC);
-        const lvi_pt ori = *qp;
-        int id[5] = {-1, -1, -1, -1, -1};
-        float4 pp[5];
-        float4 ref = make_float4(0.f, 0.f, 0.f, 0.f), f1 = ref, f2 = ref;
-        unsigned fok = 0u;
+    constexpr unsigned PERM_ID = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
+    // ---- phase 0, first half: the loads of the feature's record, in flight while the head of the launch runs
+    const int ql = threadIdx.x;
+    const int t = wg * QPB + ql;
+    const bool lane_feat = ql < QPB;
+    const bool active = lane_feat && t < Q;
+    const int tc = (lane_feat && t < Q) ? t : Q - 1;
+    lvi_pt ori = {0.f, 0.f, 0.f, 0.f};
+    int id[5] = {-1, -1, -1, -1, -1};
+    float4 pp[5];
+    float4 ref = make_float4(0.f, 0.f, 0.f, 0.f), f1 = ref, f2 = ref;
+    unsigned fok = 0u;
 #pragma unroll
-        for (int j = 0; j < 5; j++) pp[j] = ref;
+    for (int j = 0; j < 5; j++) pp[j] = ref;
+    if (lane_feat) {
+        const lvi_pt* qp = tc < nC ? a.q[0] + tc : a.q[1] + (tc - nC);
+        ori = *qp;
         if (use_prev) {                                     // uniform: one round of loads, all in flight together
 #pragma unroll
             for (int j = 0; j < 5; j++) { id[j] = a.nn_prev[(size_t)j * cap + tc]; pp[j] = a.nn_pt[(size_t)j * cap + tc]; }
             if (a.nn_ref) ref = a.nn_ref[tc];
             f1 = a.fit[tc]; f2 = a.fit2[tc]; fok = a.fit_ok[tc];
         }
+    }
+    // ---- H: the end of iteration iter - 1
+    if constexpr (FIRST) {
+        if (threadIdx.x < 12) sA[threadIdx.x] = poseA;
+        if (threadIdx.x < 6) sT[threadIdx.x] = poseT;
+        if (threadIdx.x == 0) sdone = 0;
+    } else if (threadIdx.x < 64) {
+        // The totals the previous launch left (exact integers: the same in every workgroup, whatever order they were added in),
+        // the 6 x 6 solve, the new pose.  No workgroup waits for another one.
+        const long long tq0 = stamp ? clock64() : 0;
+        IcpPose P;
+#pragma unroll
+        for (int k = 0; k < 6; k++) P.T[k] = rdl(tin, k);
+        icp_take_sums(a, iter - 1, threadIdx.x, ssum, stmp);
+        const long long tq1 = stamp ? clock64() : 0;
+        const int dn = icp_iter_end(a, iter - 1, ssum, threadIdx.x, wg == 0, degen_in, P);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) sA[k] = P.A[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) sT[k] = P.trig[k];
+            sdone = dn;
+        }
+        if (stamp) { const long long tq2 = clock64(); a.cyc[8] = tq1 - tq0; a.cyc[9] = tq2 - tq1; a.cyc[12] = tq2 - tq0; }
+    }
+    // the buffer the NEXT launch adds into (last read by the previous launch)
+    if (wg == 0) { unsigned long long* z = a.acc + (size_t)((iter + 1) % 3) * (ICP_SHARDS * 56); for (int k = threadIdx.x; k < ICP_SHARDS * 56; k += NT) z[k] = 0ull; }
+    __syncthreads();
+    if (sdone) return;
+    LVI_STAMP(0);
+    // ---- phase 0, second half.  From the second iteration on a feature knows its previous five neighbours; their distances
+    // under the new pose bound the fifth-nearest distance (five map points lie inside that ball), and the search either shrinks
+    // to that ball or is not needed at all: the feature's last search left a lower bound LB on the distance from where it stood
+    // THEN (ref) to every map point outside its five, so every such point is at least LB - |sel - ref| away now; if that exceeds
+    // the farthest of the five (with 2e-4 m of room for the f32 rounding of the distances, 1e-6 relative), the five are still
+    // the five nearest, no outsider can even tie, and their (distance, index) order is recomputed here with the search's own
+    // expression: the same Knn5, bit for bit, without a search.
+    if (lane_feat) {
         const lvi_pt sel = to_map(sA, ori);
         bool need = active;
         float r2 = KNN_R2_FULL;
-        unsigned perm = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
+        unsigned perm = PERM_ID;
         KnnKeys kk;
 #pragma unroll
         for (int j = 0; j < 5; j++) kk.k[j] = KNN_EMPTY;
@@ -1078,7 +1152,7 @@ __global__ __launch_bounds__(64 * G) void icp_gn_kernel(Batch<IcpArgs> B_, int i
                 sd[j][ql] = __uint_as_float((unsigned)(kk.k[j] >> 32)); si[j][ql] = (int)(lo >> 3);
                 perm |= (lo & 7u) << (3 * j);
             }
-            srefit[ql] = (perm != (0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12)) || fok == 0u) ? 1 : 0;
+            srefit[ql] = (perm != PERM_ID || fok == 0u) ? 1 : 0;
         }
         if (!active) {
 #pragma unroll
@@ -1088,76 +1162,83 @@ __global__ __launch_bounds__(64 * G) void icp_gn_kernel(Batch<IcpArgs> B_, int i
 #pragma unroll
         for (int j = 0; j < 5; j++) { spt[j][0][ql] = pp[j].x; spt[j][1][ql] = pp[j].y; spt[j][2][ql] = pp[j].z; sidr[j][ql] = id[j]; }
         sori[0][ql] = ori.x; sori[1][ql] = ori.y; sori[2][ql] = ori.z; sori[3][ql] = ori.intensity;
-        sf1[0][ql] = f1.x; sf1[1][ql] = f1.y; sf1[2][ql] = f1.z; sf1[3][ql] = f1.w;
-        sf2[0][ql] = f2.x; sf2[1][ql] = f2.y; sf2[2][ql] = f2.z; sf2[3][ql] = f2.w;
-        sperm[ql] = perm; sfok[ql] = (unsigned char)fok;
+        sperm[ql] = (unsigned short)perm; sfok[ql] = (unsigned char)fok;
+        // the searching features, listed in feature order: rank inside the wavefront now, the wavefronts' offsets after the barrier
         const unsigned long long mk = __ballot(need);
-        if (need) { const int pos = __popcll(mk & ((1ull << ql) - 1ull)); slist[pos] = (unsigned char)ql; sr2[pos] = r2; }
-        if (ql == 0) snsearch = __popcll(mk);
+        const int wv = ql >> 6;
+        if ((ql & 63) == 0) swcnt[wv] = __popcll(mk);
+        if (QPB == 64) { if (need) { const int pos = __popcll(mk & ((1ull << (ql & 63)) - 1ull)); slist[pos] = (unsigned short)ql; sr2[pos] = r2; } }
+        else {
+            __syncthreads();                        // (QPB == NT here: every thread is a feature lane and reaches this barrier)
+            int off = 0;
+#pragma unroll
+            for (int w = 0; w < QPB / 64; w++) off += w < wv ? swcnt[w] : 0;
+            if (need) { const int pos = off + __popcll(mk & ((1ull << (ql & 63)) - 1ull)); slist[pos] = (unsigned short)ql; sr2[pos] = r2; }
+        }
     }
-    LVI_STAMP(0);
     __syncthreads();
-    // Phase A: G lanes per SEARCHING feature, packed to the front of the workgroup (wavefronts beyond the list have nothing to do)
+    int nsearch = 0;
+#pragma unroll
+    for (int w = 0; w < QPB / 64; w++) nsearch += swcnt[w];
+    LVI_STAMP(6);
+    // ---- phase A: G lanes per SEARCHING feature, NT / G features per round
     {
-        const int gi = threadIdx.x / G, sub = threadIdx.x % G;
         long long tk[6] = {0, 0, 0, 0, 0, 0};
         float r2 = KNN_R2_FULL;
-        if (gi < snsearch) {
-            const int ql = slist[gi];
-            const int t = wg * ICP_QPB + ql;
-            const int w = t < nC ? 0 : 1;
-            lvi_pt ori; ori.x = sori[0][ql]; ori.y = sori[1][ql]; ori.z = sori[2][ql]; ori.intensity = 0.f;
-            const lvi_pt sel = to_map(sA, ori);
-            r2 = sr2[gi];
-            Knn5 r;
-            float lb2 = 0.f;
-            knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
-            if (sub == 0) {
-                const bool five = r.d[4] < 1.0f;
-                // the same five in the same order as the record (a search usually confirms them): its coordinates and its fit stand
-                bool same = five && use_prev && sfok[ql] != 0;
+        for (int base = 0; base < nsearch; base += NT / G) {
+            const int gi = base + threadIdx.x / G, sub = threadIdx.x % G;
+            if (gi < nsearch) {
+                const int qs = slist[gi];
+                const int ts = wg * QPB + qs;
+                const int w = ts < nC ? 0 : 1;
+                lvi_pt o2; o2.x = sori[0][qs]; o2.y = sori[1][qs]; o2.z = sori[2][qs]; o2.intensity = 0.f;
+                const lvi_pt sel = to_map(sA, o2);
+                r2 = sr2[gi];
+                Knn5 r;
+                float lb2 = 0.f;
+                knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
+                if (sub == 0) {
+                    const bool five = r.d[4] < 1.0f;
+                    // the same five in the same order as the record (a search usually confirms them): its coordinates and its fit stand
+                    bool same = five && use_prev && sfok[qs] != 0;
 #pragma unroll
-                for (int j = 0; j < 5; j++) same = same && r.i[j] == sidr[j][ql];
-                if (!same) {
-                    const lvi_pt* __restrict__ map = a.mapds[w];
-                    lvi_pt nbp[5];
+                    for (int j = 0; j < 5; j++) same = same && r.i[j] == sidr[j][qs];
+                    if (!same) {
+                        const lvi_pt* __restrict__ map = a.mapds[w];
+                        lvi_pt nbp[5];
 #pragma unroll
-                    for (int j = 0; j < 5; j++) nbp[j] = map[five ? r.i[j] : 0];           // unconditional: the five loads travel together
+                        for (int j = 0; j < 5; j++) nbp[j] = map[five ? r.i[j] : 0];           // unconditional: the five loads travel together
 #pragma unroll
-                    for (int j = 0; j < 5; j++) { spt[j][0][ql] = nbp[j].x; spt[j][1][ql] = nbp[j].y; spt[j][2][ql] = nbp[j].z; }
+                        for (int j = 0; j < 5; j++) { spt[j][0][qs] = nbp[j].x; spt[j][1][qs] = nbp[j].y; spt[j][2][qs] = nbp[j].z; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 5; j++) { sd[j][qs] = r.d[j]; si[j][qs] = r.i[j]; }
+                    sperm[qs] = (unsigned short)PERM_ID;
+                    srefit[qs] = same ? 0 : 1;
+                    if (a.nn_ref) a.nn_ref[ts] = make_float4(sel.x, sel.y, sel.z, five ? lb2 : 0.f);
                 }
-#pragma unroll
-                for (int j = 0; j < 5; j++) { sd[j][ql] = r.d[j]; si[j][ql] = r.i[j]; }
-                sperm[ql] = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
-                srefit[ql] = same ? 0 : 1;
-                if (a.nn_ref) a.nn_ref[t] = make_float4(sel.x, sel.y, sel.z, five ? lb2 : 0.f);
             }
         }
         LVI_STAMP(1);
-        if (stamp) { cyc[6] = tk[1] - tk[0]; cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; a.cyc[13] = tk[5]; a.cyc[14] = r2 < KNN_R2_FULL ? 1 : 0; }
-        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&a.cyc[15], (unsigned long long)snsearch);      // searches of this scan match, all iterations
+        if (stamp) { cyc[7] = tk[2] - tk[1]; cyc[2] = tk[3] - tk[2]; a.cyc[13] = tk[5]; a.cyc[14] = r2 < KNN_R2_FULL ? 1 : 0; }
+        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&a.cyc[15], (unsigned long long)nsearch);      // searches of this scan match, all iterations
     }
     __syncthreads();
-    // Phase B, first wavefront, one lane per feature
-    if (threadIdx.x < ICP_QPB) {
-        const int ql = threadIdx.x;
-        const int t = wg * ICP_QPB + ql;
-        double* row = srow + ql * ICP_ROW;
+    // ---- phase B, one lane per feature
+    if (lane_feat) {
         bool ok = false;
         float rA[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rB = 0.f;
         if (t < Q) {
             const bool isC = t < nC;
-            lvi_pt ori; ori.x = sori[0][ql]; ori.y = sori[1][ql]; ori.z = sori[2][ql]; ori.intensity = sori[3][ql];
             const lvi_pt sel = to_map(sA, ori);
             const bool five = sd[4][ql] < 1.0f;                                    // :1025, :1121
             const bool refit = srefit[ql] != 0;
             const unsigned perm = sperm[ql];
-            lvi_pt nb[5];
-#pragma unroll
-            for (int j = 0; j < 5; j++) { const int m = (perm >> (3 * j)) & 7u; nb[j].x = spt[m][0][ql]; nb[j].y = spt[m][1][ql]; nb[j].z = spt[m][2][ql]; nb[j].intensity = 0.f; }
-            float4 f1 = make_float4(sf1[0][ql], sf1[1][ql], sf1[2][ql], sf1[3][ql]), f2 = make_float4(sf2[0][ql], sf2[1][ql], sf2[2][ql], sf2[3][ql]);
-            unsigned fok = sfok[ql];
+            fok = sfok[ql];
             if (refit) {
+                lvi_pt nb[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) { const int m = (perm >> (3 * j)) & 7u; nb[j].x = spt[m][0][ql]; nb[j].y = spt[m][1][ql]; nb[j].z = spt[m][2][ql]; nb[j].intensity = 0.f; }
                 if (five) {
                     bool valid;
                     if (isC) valid = corner_fit(nb, f1, f2); else valid = surf_fit(nb, f1);
@@ -1177,65 +1258,67 @@ __global__ __launch_bounds__(64 * G) void icp_gn_kernel(Batch<IcpArgs> B_, int i
             if (five && fok == 1u) ok = isC ? corner_eval(f1, f2, sel, cf) : surf_eval(f1, ori, sel, cf);
             if (ok) lm_row(sT, ori, cf, rA, rB);
         }
-        {
-            int k = 0;
-#pragma unroll
-            for (int rr = 0; rr < 6; rr++)
-#pragma unroll
-                for (int c = rr; c < 6; c++) row[k++] = ok ? (double)rA[rr] * (double)rA[c] : 0.0;
-#pragma unroll
-            for (int rr = 0; rr < 6; rr++) row[21 + rr] = ok ? (double)rA[rr] * (double)rB : 0.0;
-            row[27] = ok ? 1.0 : 0.0;
-        }
+        float4* rw = reinterpret_cast<float4*>(&srow[ql][0]);
+        rw[0] = ok ? make_float4(rA[0], rA[1], rA[2], rA[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rw[1] = ok ? make_float4(rA[4], rA[5], rB, 1.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     LVI_STAMP(3);
     __syncthreads();
-    // Phase C: 4 x 16 rows, then the four group sums, in that fixed shape; the sums join the launch's totals as exact integers
-    if (threadIdx.x < 128) {
-        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    // ---- phase C: column k of the 28 (21 products of AtA, 6 of AtB, the count) over 16 consecutive features, in feature order,
+    // in f64; that sum is turned into exact fixed point, and from there on everything is integer: the totals of a launch do not
+    // depend on the features per workgroup, on the lanes per feature, on the XCD placement or on arrival order
+    constexpr int NG = QPB / 16;                    // groups of 16 features (aligned to the feature index)
+    for (int idx = threadIdx.x; idx < NG * 32; idx += NT) {
+        const int k = idx & 31, g = idx >> 5;
         if (k < 28) {
+            int r = (k >= 6) + (k >= 11) + (k >= 15) + (k >= 18) + (k >= 20);
+            int c = r + (k - (r * 6 - (r * (r - 1)) / 2));
+            if (k >= 21) { r = k - 21; c = 6; }
+            if (k == 27) { r = 7; c = 7; }
             double v = 0.0;
 #pragma unroll
-            for (int q = 0; q < 16; q++) v += srow[(g * 16 + q) * ICP_ROW + k];
-            spart[g][k] = v;
+            for (int q = 0; q < 16; q++) v += (double)srow[g * 16 + q][r] * (double)srow[g * 16 + q][c];
+            long long co, fi;
+            fx_split(v, co, fi);
+            spi[g][k] = co; spi[g][28 + k] = fi;
         }
     }
     __syncthreads();
-    if (threadIdx.x < ICP_QPB) {                       // the first wavefront: adds, drain, ticket
-        if (threadIdx.x < 28) {
-            const double v = ((spart[0][threadIdx.x] + spart[1][threadIdx.x]) + spart[2][threadIdx.x]) + spart[3][threadIdx.x];
-            long long co, fi;
-            fx_split(v, co, fi);
-            if (co) atomicAdd(&a.acc[threadIdx.x], (unsigned long long)co);
-            if (fi) atomicAdd(&a.acc[28 + threadIdx.x], (unsigned long long)fi);
-        }
-        // the adds of this wavefront are performed at the memory side before its ticket is drawn (vmcnt counts an atomic
-        // until its acknowledgement): the workgroup whose ticket is the last one finds every workgroup's adds in the totals
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) slast = (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nb - 1)) ? 1 : 0;
+    if (threadIdx.x < 56) {
+        long long tot = 0;
+#pragma unroll
+        for (int g = 0; g < NG; g++) tot += spi[g][threadIdx.x];
+        unsigned long long* dst = a.acc + (size_t)(iter % 3) * (ICP_SHARDS * 56) + (size_t)(wg & (ICP_SHARDS - 1)) * 56;
+        if (tot) atomicAdd(&dst[threadIdx.x], (unsigned long long)tot);       // no one waits for these: the next launch reads the totals
     }
     LVI_STAMP(4);
     if (stamp) { cyc[5] = clock64() - t_first; for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q]; }
 #undef LVI_STAMP
-    __syncthreads();
-    if (!slast || threadIdx.x >= 64) return;
-    {
-        const long long tq0 = clock64();
-        // the totals, taken with an exchange (executed where the adds were executed; leaves the accumulators zero for the next launch)
-        if (threadIdx.x < 56) {
-            const unsigned long long v = atomicExch(&a.acc[threadIdx.x], 0ull);
-            srow[threadIdx.x] = ldexp((double)(long long)v, threadIdx.x < 28 ? -16 : -60);
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_block(); __builtin_amdgcn_wave_barrier();      // one wavefront: its LDS operations complete in order
-        if (threadIdx.x < 28) ssum[threadIdx.x] = srow[threadIdx.x] + srow[28 + threadIdx.x];
-        __threadfence_block(); __builtin_amdgcn_wave_barrier();
-        const long long tq1 = clock64();
-        icp_solve_tail(a, iter, last, ssum);
-        if (a.cyc && iter == 1 && threadIdx.x == 0) { const long long tq2 = clock64(); a.cyc[8] = tq1 - tq0; a.cyc[9] = tq2 - tq1; a.cyc[12] = tq2 - tq0; }
-    }
 }
 
+// After the last Gauss-Newton launch: the end of its iteration (unless the loop ended earlier), transformUpdate, the pose
+// record.  One wavefront per scan.
+__global__ __launch_bounds__(64) void icp_final_kernel(Batch<IcpArgs> B_, int n_iters)
+{
+    const IcpArgs& a = B_.a[blockIdx.z];
+    IcpState& s = *a.st;
+    __shared__ double ssum[28], tmp[56];
+    if (n_iters <= 0) {                                                            // no loop at all: the gates alone decide the status
+        if (threadIdx.x == 0) {
+            if (!a.have_map) s.status = LVI_NO_MAP;                                                           // :1317
+            else if (!(a.nq[0] > a.edgeMin && a.nq[1] > a.surfMin)) s.status = LVI_TOO_FEW_FEATURES;          // :1320
+        }
+    } else if (!s.done) {
+        IcpPose P;
+        const IcpPose& pin = s.pose[(n_iters - 1) & 1];
+#pragma unroll
+        for (int k = 0; k < 6; k++) P.T[k] = pin.T[k];
+        icp_take_sums(a, n_iters - 1, threadIdx.x, ssum, tmp);
+        (void)icp_iter_end(a, n_iters - 1, ssum, threadIdx.x, true, s.degenerate, P);
+    }
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x == 0) icp_finish_body(a);
+}
 
 __global__ __launch_bounds__(256) void transform_kernel(const lvi_pt* in, int n, IcpPose pose, lvi_pt* out)
 {
@@ -1293,7 +1376,7 @@ IcpArgs icp_args(LidarDev& d)
     for (int w = 0; w < 2; w++) { a.meta[w] = d.grid[w].meta; a.cell_start[w] = d.grid[w].cell_start; a.sorted[w] = d.grid[w].sorted; }
     a.mapds[0] = d.mapCornerDS; a.mapds[1] = d.mapSurfDS;
     a.cyc = d.d_icp_cycles; a.d_status = d.d_status; a.nn_prev = d.knn_bound ? d.nnPrev : nullptr;
-    a.cap = d.ext_cap; a.nn_pt = d.nnPt; a.fit = d.fitA; a.fit2 = d.fitB; a.fit_ok = d.fitOk; a.acc = d.icpAcc; a.ticket = d.icpTicket;
+    a.cap = d.ext_cap; a.nn_pt = d.nnPt; a.fit = d.fitA; a.fit2 = d.fitB; a.fit_ok = d.fitOk; a.acc = d.icpAcc;
     a.nn_ref = (d.knn_bound && d.knn_skip) ? d.nnRef : nullptr; a.knn_slack = d.knn_slack;
     { static const bool no_map = getenv("LVI_ICP_NO_XCD_MAP") != nullptr; a.xcd_map = no_map ? 0 : 1; }
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
@@ -1515,11 +1598,11 @@ void set_pose_init(const Slots& sl, const float* p, bool clear_status)
         B.a[z].dst = sl[z].d_pose_init;
         for (int k = 0; k < 6; k++) B.a[z].t[k] = p[6 * z + k];
         B.a[z].d_status = clear_status ? sl[z].d_status : nullptr;
-        B.a[z].st = sl[z].icp; B.a[z].cyc = sl[z].d_icp_cycles; B.a[z].acc = sl[z].icpAcc; B.a[z].ticket = sl[z].icpTicket;
+        B.a[z].st = sl[z].icp; B.a[z].cyc = sl[z].d_icp_cycles; B.a[z].acc = sl[z].icpAcc;
     }
     for (int z = sl.n; z < MAX_BATCH; z++) B.a[z] = B.a[0];
     const Ctx& cx = sl.first().ctx;
-    hipLaunchKernelGGL(set_pose_init_kernel, dim3(1, 1, sl.n), dim3(1), 0, cx.stream, B);
+    hipLaunchKernelGGL(set_pose_init_kernel, dim3(1, 1, sl.n), dim3(64), 0, cx.stream, B);
     LVI_HIP(hipGetLastError());
 }
 void set_pose_init(LidarDev& d, const float p[6]) { set_pose_init(OneSlot(d).s, p, false); }
@@ -1548,17 +1631,30 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
         // (the grid covers ext_cap features; the ~1 200 workgroups beyond the actual count exit at once — measured: launching
         // exactly the occupied 360 instead changes nothing)
         // iteration 0 searches the unit ball; later iterations search the (much smaller) ball of the previous neighbours, where
-        // the per-lane fixed cost dominates: fewer lanes per feature (d.icp_g1).  The solve, the pose update and — in the last
-        // launch — transformUpdate run in the workgroup that arrives last: ONE launch per Gauss-Newton iteration.
+        // the per-lane fixed cost dominates: fewer lanes per feature (d.icp_g1).  The solve and the pose update of an iteration run at
+        // the head of the NEXT launch, in every workgroup: ONE launch per Gauss-Newton iteration, no workgroup waits for another.
         const int G1 = it == 0 ? d.icp_g0 : d.icp_g1;
-        const int lastf = it == a.max_iters - 1 ? 1 : 0;
-        const dim3 rg((d.nblk_icp + 7) & ~7, 1, S);               // a multiple of 8: the kernel deals its workgroups to the XCDs in contiguous ranges
-        if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<8, 8>), rg, dim3(512), 0, cx.stream, B, it, lastf));
-        else if (G1 == 4) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<4, 4>), rg, dim3(256), 0, cx.stream, B, it, lastf));
-        else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<2, 4>), rg, dim3(128), 0, cx.stream, B, it, lastf));
-        else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<8, 4>), rg, dim3(512), 0, cx.stream, B, it, lastf));
+        // a multiple of 8 workgroups: the kernel deals them to the XCDs in contiguous ranges
+        // iteration 0 and the two after it search nearly everything (the first corrections move a feature 20 m out by half a metre):
+        // 64 features per workgroup, many workgroups; later iterations mostly skip their searches: 256 features per workgroup
+        if (it == 0) {
+            const dim3 rg((div_up(d.ext_cap, 64) + 7) & ~7, 1, S);
+            if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 8, 8>), rg, dim3(512), 0, cx.stream, B, it));
+            else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 2, 4>), rg, dim3(128), 0, cx.stream, B, it));
+            else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
+        } else if (it < d.icp_wide_from) {
+            const dim3 rg((div_up(d.ext_cap, 64) + 7) & ~7, 1, S);
+            if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 8, 4>), rg, dim3(512), 0, cx.stream, B, it));
+            else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 2, 4>), rg, dim3(128), 0, cx.stream, B, it));
+            else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
+        } else {
+            const dim3 rg((div_up(d.ext_cap, 256) + 7) & ~7, 1, S);
+            if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 8, 4>), rg, dim3(256), 0, cx.stream, B, it));
+            else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 2, 4>), rg, dim3(256), 0, cx.stream, B, it));
+            else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
+        }
     }
-    if (a.max_iters <= 0) LVI_LAUNCH(cx, "icp_finish", 0, hipLaunchKernelGGL(icp_finish_kernel, dim3(1, 1, S), dim3(1), 0, cx.stream, B));
+    LVI_LAUNCH(cx, "icp_final", 0, hipLaunchKernelGGL(icp_final_kernel, dim3(1, 1, S), dim3(64), 0, cx.stream, B, a.max_iters));
 }
 void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record) { stage_scan_match_enqueue(OneSlot(d).s, imu, d_record); }
 
@@ -1574,16 +1670,16 @@ void debug_residuals(LidarDev& d, int which, const float pose[6])
 {
     join_map(d);
     IcpArgs a = icp_args(d);
-    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->pose, pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]);
-    hipLaunchKernelGGL(residual_debug_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a, which, &d.icp->pose, d.coeff, d.flag);
+    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->scratch, pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]);
+    hipLaunchKernelGGL(residual_debug_kernel, dim3(d.nblk_icp), dim3(ICP_BLOCK), 0, d.ctx.stream, a, which, &d.icp->scratch, d.coeff, d.flag);
     LVI_HIP(hipGetLastError());
 }
 
 void transform_cloud(LidarDev& d, const lvi_pt* d_in, int n, const float pose6[6], lvi_pt* d_out)
 {
-    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->pose, pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5]);
+    hipLaunchKernelGGL(pose_only_kernel, dim3(1), dim3(1), 0, d.ctx.stream, &d.icp->scratch, pose6[0], pose6[1], pose6[2], pose6[3], pose6[4], pose6[5]);
     LVI_LAUNCH(d.ctx, "transform_cloud", 32.0 * n, hipLaunchKernelGGL(transform_dev_pose_kernel, dim3(div_up(std::max(n, 1), 256)), dim3(256), 0, d.ctx.stream,
-                                                                     d_in, n, &d.icp->pose, d_out));
+                                                                     d_in, n, &d.icp->scratch, d_out));
 }
 
 }  // namespace lvi

@@ -24,7 +24,9 @@ struct IcpPose {                         // written by icp_solve for the next re
 };
 
 struct IcpState {                        // device, one per handle
-    IcpPose pose;
+    IcpPose pose[2];                     // pose of Gauss-Newton iteration i in pose[i & 1] (a launch reads one buffer and writes the other)
+    int cur;                             // buffer of the latest pose (transformUpdate reads it)
+    IcpPose scratch;                     // lvi_transform_cloud / lvi_debug_residuals
     int done;                            // LMOptimization returned true (and break enabled) or loop skipped
     int converged, degenerate, iters, any_lm, status;
     int n_sel[LVI_ICP_MAX_ITERS];
@@ -103,8 +105,7 @@ struct LidarDev {
     unsigned* genKeysDbg = nullptr;
     // ---- icp
     IcpState* icp = nullptr;
-    unsigned long long* icpAcc = nullptr;                  // [56] exact fixed-point totals of the 28 sums of one GN launch (coarse, fine), zero between launches
-    unsigned* icpTicket = nullptr;                         // [1] arrival ticket of the GN launch, zero between launches
+    unsigned long long* icpAcc = nullptr;                  // [3][8][56] exact fixed-point totals of the 28 sums of a GN launch (coarse, fine): 8 shards, 3 buffers in rotation
     lvi_pt* coeff = nullptr; uint8_t* flag = nullptr;      // [ext_cap] lvi_debug_residuals only
     int* nnPrev = nullptr;                                 // [5][ext_cap] the five neighbours of the feature's last search, in its fit's order
     float4* nnPt = nullptr;                                // [5][ext_cap] their coordinates
@@ -112,6 +113,7 @@ struct LidarDev {
     unsigned char* fitOk = nullptr;                        // [ext_cap]
     int icp_g0 = 4;                                        // lanes per feature in GN iteration 0 (whole unit ball; LVI_ICP_G0; measured with 16 scans in flight: 8 lanes 5 030, 4 lanes 5 245 scans/s)
     int icp_g1 = 4;                                        // lanes per feature in GN iterations >= 1 (LVI_ICP_G1 = 8 | 4 | 2 | 84 (8 lanes, batches of 4))
+    int icp_wide_from = 3;                                 // first GN iteration that runs 256 features per workgroup (LVI_ICP_WIDE_FROM)
     float4* nnRef = nullptr;                               // [ext_cap] position at the feature's last search + squared lower bound on the distance to the map points outside its five
     bool knn_skip = true;                                  // LVI_KNN_NO_SKIP=1 at create: every iteration >= 1 runs its (bounded) search (tests: same bits)
     float knn_slack = 0.05f;                               // LVI_KNN_SLACK (m): radius added to a bounded search so that later iterations can skip theirs

@@ -930,7 +930,7 @@ void layout(AR& ar, LidarDev& d)
     d.d_kfSeg = ar.template alloc<LidarDev::KfSeg>((size_t)std::max(d.kf_seg_cap, 1));
     d.icp = ar.template alloc<IcpState>(1);
     d.d_pose_init = ar.template alloc<float>(8);
-    d.icpAcc = ar.template alloc<unsigned long long>(64); d.icpTicket = ar.template alloc<unsigned>(4);
+    d.icpAcc = ar.template alloc<unsigned long long>(3 * 8 * 56);
     d.coeff = ar.template alloc<lvi_pt>(d.ext_cap); d.flag = ar.template alloc<uint8_t>(d.ext_cap);
     d.nnPrev = ar.template alloc<int>((size_t)d.ext_cap * 5);
     d.nnRef = ar.template alloc<float4>((size_t)d.ext_cap);
@@ -973,8 +973,10 @@ void lidar_allocate(LidarDev& d)
     { const char* e = getenv("LVI_KNN_NO_SKIP"); d.knn_skip = !(e && e[0] == '1'); }
     { const char* e = getenv("LVI_KNN_SLACK"); if (e) d.knn_slack = std::max(0.f, (float)atof(e)); }
     { const char* e = getenv("LVI_VB_BINS"); if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && b <= VB_NB) { d.voxMap.bin_pts = a; d.voxMap.bin_max = b; } } }
-    if (d.P.batch_scans > 1) d.icp_g1 = 2;        // throughput mode: 16 scans in flight 5 315 scans/s with 2 lanes, 5 140 with 4; one scan alone: 25 vs 20 us per iteration
+    if (d.P.batch_scans > 1) { d.icp_g1 = 2; d.icp_wide_from = 1; }      // (256 features per workgroup from iteration 1 on: 8 040 vs 7 930 scans/s; a single scan: 640 vs 612 us)
+    // (2 lanes per feature in throughput mode: 16 scans in flight 5 315 scans/s with 2 lanes, 5 140 with 4; one scan alone: 25 vs 20 us per iteration)
     { const char* e = getenv("LVI_ICP_G0"); if (e) d.icp_g0 = atoi(e); }
+    { const char* e = getenv("LVI_ICP_WIDE_FROM"); if (e) d.icp_wide_from = std::max(1, atoi(e)); }
     { const char* e = getenv("LVI_ICP_G1"); if (e) d.icp_g1 = atoi(e); if (!d.knn_bound) d.icp_g1 = 8; }
     d.feat_handover_ticks = d.P.sector_handover_wait_us < 0 ? 0 : 100ll * (d.P.sector_handover_wait_us > 0 ? d.P.sector_handover_wait_us : 2000);
     d.nblk_icp = div_up(d.ext_cap, ICP_BLOCK / KNN_G);

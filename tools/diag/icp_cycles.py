@@ -18,7 +18,7 @@ g0.close()
 pose = S.loop_pose(0.37, 0.0, -0.02)
 scan = S.make_scan(100001, pose, 12345)
 guess = S.perturbed_guess(pose, 0)
-names = ["pose", "knn_total", "merge", "residual", "reduce", "total", "row_setup", "first_batch", "s_part", "s_comb", "s_solve", "s_pose", "s_total", "T", "bounded", "searches"]
+names = ["phase0", "knn_total", "merge", "fit_rows", "reduce_ticket", "total", "row_setup", "first_batch", "s_take", "s_solve", "", "", "s_total", "T", "bounded", "searches"]
 for nb, g1 in (("0", os.environ.get("LVI_ICP_G1", "4")),):
     os.environ["LVI_ICP_G1"] = g1
     os.environ["LVI_KNN_NO_BOUND"] = nb
@@ -33,5 +33,5 @@ for nb, g1 in (("0", os.environ.get("LVI_ICP_G1", "4")),):
     g.prof_enable(True)
     g.scan_upload(scan); g.scan_organize(); g.scan_extract(); g.scan_downsample(); g.scan_match(guess)
     st = {s["name"]: (s["launches"], round(1e3 * s["total_ms"] / s["launches"], 2)) for s in g.prof_read()}
-    print("   ", {k: st[k] for k in ("icp_residual", "icp_solve")})
+    print("   ", {k: st[k] for k in ("icp_gn", "set_pose_init") if k in st})
     g.close()
