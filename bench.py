@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-ROUND = "r02"                # profiles/<ROUND>_pmc_traffic.json carries this round's HBM counter traffic
+ROUND = "r03"                # profiles/<ROUND>_pmc_traffic.json carries this round's HBM counter traffic
 
 
 def parse():
@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--map-source", choices=["resident", "assemble"], default="resident",
                     help="resident: the raw local map sits in HBM as one cloud (headline); assemble: it is fused per step from the "
                          "device-resident keyframe store (SURVEY f-4: what a node does instead of uploading 78 MB per scan)")
+    ap.add_argument("--map-plan", choices=["per-rebuild", "cached"], default="per-rebuild",
+                    help="per-rebuild (headline): every re-voxelisation of the raw map takes the bounding box (getMinMax3D) and the per-bin counts "
+                         "again, per scan, as the reference's VoxelGrid::filter does; cached: once per map upload (lvi_lidar_params.map_plan_cache = 1)")
+    ap.add_argument("--cached-plan-steps", type=int, default=12, help="secondary figure: steps timed once more with map_plan_cache = 1 (0 = skip)")
     ap.add_argument("--icp-iters", type=int, default=10)
     ap.add_argument("--pool", type=int, default=8, help="distinct scans per rank, cycled")
     ap.add_argument("--queue-depth", type=int, default=2,
@@ -105,7 +109,7 @@ def main():
     B = max(1, args.inflight)
     NB = max(1, min(args.batch, 8))
     P = dict(N_SCAN=4, Horizon_SCAN=32768, max_raw_points=131072, max_map_points=args.map_points + 65536,
-             icp_max_iters=args.icp_iters, icp_disable_break=1, batch_scans=NB,
+             icp_max_iters=args.icp_iters, icp_disable_break=1, batch_scans=NB, map_plan_cache=(1 if args.map_plan == "cached" else 0),
              map_on_main_stream=(1 if B * NB >= 4 else 0) if args.map_stream < 0 else args.map_stream,   # one stream per hardware queue once >= 4 scans are in flight
              max_keyframes=(args.keyframes + 8) if args.map_source == "assemble" else 0,
              max_keyframe_points=(args.map_points + 200000) if args.map_source == "assemble" else 0)
@@ -374,8 +378,11 @@ def main():
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * elapsed / args.steps, 4),
         higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
         config=dict(workload=("lidar_odometry scan-to-map, reference-faithful per scan: organise + LOAM feature extraction + voxel grids "
-                              "+ re-voxelisation of the raw local map + KNN index build + %d GN iterations" % args.icp_iters)
+                              "+ re-voxelisation of the raw local map (%s) + KNN index build + %d GN iterations"
+                              % ("bounding box and per-bin counts taken inside every rebuild, per scan" if args.map_plan == "per-rebuild" else
+                                 "bounding box and per-bin counts taken ONCE per map upload: less than the reference does per scan", args.icp_iters))
                     if rebuild else "lidar_odometry scan-to-map with a frozen downsampled map (DS + index reused)",
+                    map_plan=args.map_plan if rebuild else "n/a",
                     n_raw=args.n_raw, map_raw_points=nc + ns, map_ds_points=Mds,
                     scan_features=dict(corner=C0, surf=S1, corner_ds=Cd, surf_ds=Sd),
                     icp_iters=args.icp_iters, map_source=args.map_source, handles_per_gpu=B, scans_per_launch_sequence=NB,
@@ -459,6 +466,33 @@ def main():
             out["tracker"]["cpu_oracle_frames_per_sec"] = round(nfr / (time.perf_counter() - t1), 2)
             ot.close()
 
+    # ---------------------------------------------------------------- secondary: the same steps with the map plan cached per upload
+    if rebuild and args.map_plan == "per-rebuild" and args.cached_plan_steps > 0 and args.map_source == "resident":
+        for h in hs:
+            h.close()
+        P2 = dict(P); P2["map_plan_cache"] = 1
+        hs2 = [pkg.LidarHotpath(hip, device=local_rank, **P2) for _ in range(B)]
+        for b, h in enumerate(hs2):
+            if b == 0 or args.no_share_map:
+                h.map_upload_device(d_mc.data_ptr(), nc, d_ms.data_ptr(), ns)
+            else:
+                h.map_share(hs2[0])
+            h.map_build(); h.sync()
+        roll2 = R.RollingReplay(hs2, issue, lambda j: None, depth=args.queue_depth)
+        w2 = max(args.warmup, 3) + min(n_prime, 40)            # fresh handles: the runtime's one-off stall is primed away again
+        for i in range(w2):
+            roll2.step(i)
+        roll2.flush(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.cached_plan_steps):
+            roll2.step(w2 + i)
+        roll2.flush(); torch.cuda.synchronize()
+        el2 = time.perf_counter() - t0
+        out["value_cached_plan"] = dict(scans_per_sec=round(per_step * args.cached_plan_steps / el2, 2), steps=args.cached_plan_steps, this_rank_only=True,
+                                        note="lvi_lidar_params.map_plan_cache = 1: bounding box, per-bin counts and partition offsets of the raw map computed once "
+                                             "per upload (what round 2's headline measured); not the headline")
+        for h in hs2:
+            h.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

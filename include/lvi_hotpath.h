@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LVI_ABI_VERSION 5
+#define LVI_ABI_VERSION 6
 
 /* ---- status codes -------------------------------------------------------- */
 #define LVI_OK                        0
@@ -103,6 +103,12 @@ typedef struct lvi_lidar_params {
     /* Capacity of the batched entry points (lvi_scan_batch_*): scans processed side by side by ONE launch sequence, every
      * kernel carrying the scan index in blockIdx.z.  1 (default) = no batch slots beyond the handle's own. <= LVI_MAX_BATCH. */
     int32_t batch_scans;
+    /* Re-voxelisation of the raw local map (lvi_map_build, lvi_scan_batch_run / lvi_scan_replay_enqueue with rebuild_map, lvi_map_assemble).
+     * 0 (default): every rebuild computes what VoxelGrid::filter computes for every scan (mapOptimization.cpp:958-965): the bounding box
+     * (getMinMax3D) and the per-bin point counts, then partition and centroids — per batch slot.  1: bounding box, per-bin counts and partition
+     * offsets are computed once, when the raw map is written (upload / assembly), and re-used by every rebuild of the unchanged map — the
+     * same output bits, less work than the reference does; for replay against a frozen raw map.  Only the HIP backend reads it. */
+    int32_t map_plan_cache;
 } lvi_lidar_params;
 #define LVI_MAX_BATCH 8
 

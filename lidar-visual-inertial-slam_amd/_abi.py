@@ -48,7 +48,7 @@ class LidarParams(C.Structure):
                 ("numberOfCores", C.c_int32), ("icp_max_iters", C.c_int32), ("icp_disable_break", C.c_int32),
                 ("max_raw_points", C.c_int32), ("max_map_points", C.c_int32), ("voxel_mode", C.c_int32),
                 ("max_keyframes", C.c_int32), ("max_keyframe_points", C.c_int32), ("map_on_main_stream", C.c_int32),
-                ("sector_handover_wait_us", C.c_int32), ("batch_scans", C.c_int32)]
+                ("sector_handover_wait_us", C.c_int32), ("batch_scans", C.c_int32), ("map_plan_cache", C.c_int32)]
 
 
 class ScanInfo(C.Structure):

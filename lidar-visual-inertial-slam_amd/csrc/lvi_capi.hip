@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <mutex>
 
 #include "lvi_lidar.hpp"
 
@@ -63,9 +64,12 @@ struct lvi_lidar {
     bool have_icp_host = false;
     lvi_lidar* share_owner = nullptr;               // lvi_map_share: the handle whose raw map this one reads
     std::atomic<int> shared_by{0};                  // handles that read this one's raw map (they may live on other host threads): it must not change while > 0
+    std::vector<lvi_lidar*> sharers;                // … who they are (g_share_mu): an owner that is destroyed first sends them back to their own memory
 };
 
 namespace {
+
+std::mutex g_share_mu;                              // the sharer lists of lvi_map_share (handles may live on different host threads)
 
 int32_t fail(int32_t code, const std::string& msg) { set_error(msg); return code; }
 
@@ -179,7 +183,7 @@ void lvi_lidar_params_default(lvi_lidar_params* p)
     p->icp_max_iters = 20; p->icp_disable_break = 0;
     p->max_raw_points = 131072; p->max_map_points = 1 << 20; p->voxel_mode = 0;
     p->max_keyframes = 1024; p->max_keyframe_points = 1 << 22; p->map_on_main_stream = 0;
-    p->sector_handover_wait_us = 0; p->batch_scans = 1;
+    p->sector_handover_wait_us = 0; p->batch_scans = 1; p->map_plan_cache = 0;
 }
 
 int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t device, lvi_lidar** out)
@@ -237,12 +241,23 @@ static void release_slot(LidarDev& d)
     if (d.graphExec) (void)hipGraphExecDestroy(d.graphExec);
 }
 
+static void leave_owner(lvi_lidar* h);
+static void unshare_map(lvi_lidar* h);
+
 void lvi_lidar_destroy(lvi_lidar* h)
 {
     if (!h) return;
     LidarDev& d = h->d;
     (void)hipSetDevice(d.device);
-    if (h->share_owner) { h->share_owner->shared_by--; h->share_owner = nullptr; }      // (destroying an OWNER that is still shared is the caller's error)
+    leave_owner(h);
+    // an owner that goes first: its sharers return to their own (empty) raw-map memory before this handle's is freed
+    for (;;) {
+        lvi_lidar* q = nullptr;
+        { std::lock_guard<std::mutex> lk(g_share_mu); if (!h->sharers.empty()) q = h->sharers.back(); }
+        if (!q) break;
+        try { (void)hipSetDevice(q->d.device); unshare_map(q); } catch (...) { leave_owner(q); }
+    }
+    (void)hipSetDevice(d.device);
     if (d.ctx.stream) { (void)hipStreamSynchronize(d.ctx.stream); }
     if (d.ctx2.stream) { (void)hipStreamSynchronize(d.ctx2.stream); }
     d.prof.collect();
@@ -292,6 +307,7 @@ int32_t lvi_scan_upload(lvi_lidar* h, const lvi_livox_pt* pts, int32_t n_raw)
     if (n_raw > h->cur().raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->cur();
+        d.raw_bound = nullptr;                      // (a buffer bound by lvi_scan_batch_bind_device is no longer this slot's scan)
         d.n_raw = n_raw > 0 ? n_raw - 1 : 0;        // moveFromCustomMsg: i < point_num-1 (imageProjection.cpp:249)
         // the caller's (pageable) message is copied to pinned staging on the host and uploaded from there: the call
         // returns without a stream sync, and the runtime never has to pin / stage the user's memory itself
@@ -311,6 +327,7 @@ int32_t lvi_scan_upload_device(lvi_lidar* h, const void* d_pts, int32_t n_raw)
     if (n_raw > h->cur().raw_cap) return fail(LVI_ERR_CAPACITY, "n_raw exceeds max_raw_points");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->cur();
+        d.raw_bound = nullptr;
         d.n_raw = n_raw > 0 ? n_raw - 1 : 0;
         if (d.n_raw) LVI_HIP(hipMemcpyAsync(d.raw, d_pts, sizeof(lvi_livox_pt) * (size_t)d.n_raw, hipMemcpyDeviceToDevice, d.ctx.stream));
         LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
@@ -318,22 +335,36 @@ int32_t lvi_scan_upload_device(lvi_lidar* h, const void* d_pts, int32_t n_raw)
         return LVI_OK;
     });
 }
+// A captured launch sequence (lvi_scan_replay_enqueue) froze the raw map's pointers, sizes and — with map_plan_cache — whether the
+// plan passes are part of it: whatever rewrites the raw map drops it; the next lvi_scan_replay_enqueue captures again.
+static void drop_graph(lvi_lidar* h)
+{
+    if (h->d.graphExec) { (void)hipGraphExecDestroy(h->d.graphExec); h->d.graphExec = nullptr; }
+}
 // every slot of h reads the raw local map at (c, s): the handle's own memory, or another handle's (lvi_map_share)
 static void bind_raw_map(lvi_lidar* h, lvi_pt* c, lvi_pt* s)
 {
-    // a captured launch sequence froze the old pointers (lvi_scan_replay_enqueue): it is recaptured on the next call
-    if (h->d.graphExec) { (void)hipGraphExecDestroy(h->d.graphExec); h->d.graphExec = nullptr; }
+    drop_graph(h);
     for (LidarDev* q : h->slots) {
         q->mapCornerRaw = c; q->mapSurfRaw = s;
         const VoxSegStatic st[2] = {VoxSegStatic{c, nullptr, q->mapCornerDS, q->P.mappingCornerLeafSize}, VoxSegStatic{s, nullptr, q->mapSurfDS, q->P.mappingSurfLeafSize}};
         q->voxMap.set_static(q->ctx, st);
     }
 }
+static void leave_owner(lvi_lidar* h)
+{
+    std::lock_guard<std::mutex> lk(g_share_mu);
+    if (!h->share_owner) return;
+    auto& v = h->share_owner->sharers;
+    v.erase(std::remove(v.begin(), v.end(), h), v.end());
+    h->share_owner->shared_by--;
+    h->share_owner = nullptr;
+}
 // a handle that shares another one's map goes back to its own memory before anything writes a raw map through it
 static void unshare_map(lvi_lidar* h)
 {
     if (h->d.mapCornerRaw == h->d.mapCornerOwn) return;
-    if (h->share_owner) { h->share_owner->shared_by--; h->share_owner = nullptr; }
+    leave_owner(h);
     join_map(h->d); sync(h->d);
     bind_raw_map(h, h->d.mapCornerOwn, h->d.mapSurfOwn);
     h->d.have_map_raw = false; h->d.n_map_corner = h->d.n_map_surf = 0; h->d.voxMap.bbox_cached = false;
@@ -346,12 +377,13 @@ int32_t lvi_map_share(lvi_lidar* h, lvi_lidar* owner)
     if (!owner->d.have_map_raw) return fail(LVI_ERR_STATE, "the owner holds no map");
     if (owner->d.device != h->d.device) return fail(LVI_ERR_INVALID_ARG, "handles on different GPUs");
     if (owner->d.mapCornerRaw != owner->d.mapCornerOwn) return fail(LVI_ERR_STATE, "the owner itself shares a map");
+    if (h->shared_by > 0) return fail(LVI_ERR_STATE, "other handles read this handle's map: it cannot share another one's");
     if (owner->d.n_map_corner > h->d.map_cap || owner->d.n_map_surf > h->d.map_cap) return fail(LVI_ERR_CAPACITY, "map exceeds max_map_points");
     return guarded(h, [&]() -> int32_t {
         join_map(owner->d); sync(owner->d);                         // the owner's upload / assembly has landed
         join_map(h->d); sync(h->d);
-        if (h->share_owner) h->share_owner->shared_by--;
-        h->share_owner = owner; owner->shared_by++;
+        leave_owner(h);
+        { std::lock_guard<std::mutex> lk(g_share_mu); h->share_owner = owner; owner->shared_by++; owner->sharers.push_back(h); }
         bind_raw_map(h, owner->d.mapCornerRaw, owner->d.mapSurfRaw);
         LidarDev& d = h->d;
         d.n_map_corner = owner->d.n_map_corner; d.n_map_surf = owner->d.n_map_surf; d.have_map_raw = true; d.voxMap.bbox_cached = false;
@@ -369,6 +401,7 @@ int32_t lvi_map_upload_device(lvi_lidar* h, const void* c, int32_t nc, const voi
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         unshare_map(h);
+        drop_graph(h);
         join_map(d);
         if (nc) LVI_HIP(hipMemcpyAsync(d.mapCornerRaw, c, sizeof(lvi_pt) * (size_t)nc, hipMemcpyDeviceToDevice, d.ctx.stream));
         if (ns) LVI_HIP(hipMemcpyAsync(d.mapSurfRaw, s, sizeof(lvi_pt) * (size_t)ns, hipMemcpyDeviceToDevice, d.ctx.stream));
@@ -399,6 +432,7 @@ int32_t lvi_map_upload(lvi_lidar* h, const lvi_pt* c, int32_t nc, const lvi_pt* 
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         unshare_map(h);
+        drop_graph(h);
         h2d(d, d.mapCornerRaw, c, (size_t)nc); h2d(d, d.mapSurfRaw, s, (size_t)ns);
         sync(d);
         d.n_map_corner = nc; d.n_map_surf = ns; d.have_map_raw = true; d.voxMap.bbox_cached = false; for (LidarDev* q : h->slots) q->have_map = false;
@@ -453,6 +487,7 @@ int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, 
         LidarDev& d = h->cur();
         join_map(d);
         // per-call inputs go in eagerly; the captured graph only reads fixed buffers of the handle
+        d.raw_bound = nullptr;
         d.n_raw = n_raw > 0 ? n_raw - 1 : 0;                     // moveFromCustomMsg drops the final point
         if (d.n_raw) LVI_HIP(hipMemcpyAsync(d.raw, d_pts, sizeof(lvi_livox_pt) * (size_t)d.n_raw, hipMemcpyDeviceToDevice, d.ctx.stream));
         LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
@@ -470,7 +505,7 @@ int32_t lvi_scan_replay_enqueue(lvi_lidar* h, const void* d_pts, int32_t n_raw, 
         } else {
             // everything the captured launch sequence froze: sizes, whether a map index exists (icp_init's argument) and the
             // realisation AUTO picked for each voxel plan (unknown = sorted on a plan's first batch, binned afterwards)
-            const std::array<int, 8> key = {d.n_raw, d.n_map_corner, d.n_map_surf, rebuild_map ? 1 : 0, (d.have_map || rebuild_map) ? 1 : 0,
+            const std::array<int, 8> key = {d.n_raw, d.n_map_corner, d.n_map_surf, (rebuild_map ? 1 : 0) | (d.voxMap.bbox_cached ? 2 : 0) | (d.voxMap.hist_cached ? 4 : 0), (d.have_map || rebuild_map) ? 1 : 0,
                                             voxel_resolve_mode(d.voxRing), voxel_resolve_mode(d.voxScan), voxel_resolve_mode(d.voxMap)};
             const bool stale = !d.graphExec || key != d.graph_key;
             if (stale) {
@@ -730,6 +765,7 @@ int32_t lvi_map_assemble(lvi_lidar* h, const int32_t* key_indices, int32_t n_key
     if (h->shared_by > 0) return fail(LVI_ERR_STATE, "other handles read this handle's map (lvi_map_share)");
     return guarded(h, [&]() -> int32_t {
         unshare_map(h);
+        drop_graph(h);
         stage_map_assemble(h->d, key_indices, n_keys);                                      // extractCloud's fuse loop into the raw map (slot 0)
         stage_map_build(Slots{h->slots.data(), (int)h->slots.size()});                      // + the two VoxelGrids and the index, per slot
         return LVI_OK;
@@ -741,8 +777,10 @@ int32_t lvi_map_update(lvi_lidar* h, const int32_t* key_indices, int32_t n_keys)
     if (!h || n_keys < 0 || (n_keys > 0 && !key_indices)) return fail(LVI_ERR_INVALID_ARG, "bad key list");
     for (int i = 0; i < n_keys; i++)
         if (key_indices[i] < 0 || key_indices[i] >= (int)h->d.kf_pose.size()) return fail(LVI_ERR_INVALID_ARG, "key index out of range");
+    if (h->shared_by > 0) return fail(LVI_ERR_STATE, "other handles read this handle's map (lvi_map_share)");
     bool done = false;
     int32_t st = guarded(h, [&]() -> int32_t {
+        drop_graph(h);
         done = h->slots.size() == 1 && stage_map_update(h->d, key_indices, n_keys);
         return LVI_OK;
     });
@@ -799,6 +837,7 @@ int32_t lvi_extract_features(lvi_lidar* h, const lvi_scan_info* in, lvi_cloud* c
         for (int r = 0; r < NS; r++) if (base[r] < 0 || base[r] > base[r + 1]) return fail(LVI_ERR_INVALID_ARG, "inconsistent ring indices");
         h2d(d, d.pts, in->cloud_deskewed, (size_t)n); h2d(d, d.range, in->point_range, (size_t)n); h2d(d, d.col, in->point_col_ind, (size_t)n);
         h2d(d, d.startR, in->start_ring_index, (size_t)NS); h2d(d, d.endR, in->end_ring_index, (size_t)NS);
+        d.raw_bound = nullptr;
         h2d(d, d.ringBase, base.data(), (size_t)NS + 1); h2d(d, d.d_n, &n, 1);
         LVI_HIP(hipMemsetAsync(d.d_status, 0, sizeof(int), d.ctx.stream));
         sync(d);

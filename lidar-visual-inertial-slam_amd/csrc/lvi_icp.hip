@@ -1420,9 +1420,11 @@ void stage_map_build(const Slots& sl)
         LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));
         LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
     }
-    // bbox of the raw map: one pass when the map was (re)written, not one per re-voxelisation (PCL's getMinMax3D is a pure
-    // function of the unchanged input)
-    if (!d.voxMap.bbox_cached || (!d.voxMap.hist_cached && voxel_resolve_mode(d.voxMap) == VOX_BINNED)) {      // (AUTO: the first build of a plan is sorted)
+    const bool cache_plan = d.P.map_plan_cache != 0;
+    // map_plan_cache = 1: bbox of the raw map, per-bin counts and partition offsets are taken once, when the map was (re)written (PCL's
+    // getMinMax3D is a pure function of the unchanged input).  Default (0): every re-voxelisation takes them again, per slot, as
+    // the reference's VoxelGrid::filter does for every scan (mapOptimization.cpp:958-965) — in one pass (vb_plan).
+    if (cache_plan && (!d.voxMap.bbox_cached || (!d.voxMap.hist_cached && voxel_resolve_mode(d.voxMap) == VOX_BINNED))) {      // (AUTO: the first build of a plan is sorted)
         d.voxMap.n_host[0] = d.n_map_corner; d.voxMap.n_host[1] = d.n_map_surf; d.voxMap.use_n_host = true;
         voxel_bbox_pass(cx, d.voxMap, "map", (double)d.n_map_corner + (double)d.n_map_surf);
         d.voxMap.bbox_cached = true;
@@ -1433,7 +1435,8 @@ void stage_map_build(const Slots& sl)
         LidarDev& q = sl[z];
         q.n_map_corner = d.n_map_corner; q.n_map_surf = d.n_map_surf;
         q.voxMap.n_host[0] = d.n_map_corner; q.voxMap.n_host[1] = d.n_map_surf; q.voxMap.use_n_host = true;       // instead of a 1-thread launch writing d_dyn
-        q.voxMap.bbox_cached = true; q.voxMap.hist_cached = d.voxMap.hist_cached;
+        q.voxMap.plan_per_run = !cache_plan;
+        q.voxMap.bbox_cached = cache_plan; q.voxMap.hist_cached = cache_plan && d.voxMap.hist_cached;
         plans[z] = &q.voxMap;
         q.have_map = true;
     }

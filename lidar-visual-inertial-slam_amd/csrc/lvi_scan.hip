@@ -900,10 +900,10 @@ void layout(AR& ar, LidarDev& d)
     d.mapCornerDS = ar.template alloc<lvi_pt>(d.map_cap); d.mapSurfDS = ar.template alloc<lvi_pt>(d.map_cap);
     d.voxMap.allocate(ar, 2, d.map_cap, false);
     d.voxMap.centroid_lanes = 32;
-    if (d.map_owner) {                                  // … of the shared raw map
+    if (d.map_owner && d.P.map_plan_cache) {            // … of the shared raw map: one plan for every slot
         d.voxMap.d_mmPartial = d.map_owner->voxMap.d_mmPartial; d.voxMap.d_binCountCached = d.map_owner->voxMap.d_binCountCached;
         d.voxMap.d_wprefix = d.map_owner->voxMap.d_wprefix;
-    } else {
+    } else {                                            // every slot takes its own plan inside every re-voxelisation (the default)
         d.voxMap.d_binCountCached = ar.template alloc<unsigned>((size_t)2 * VB_NB);
         d.voxMap.d_wprefix = ar.template alloc<unsigned>((size_t)2 * VB_WG * VB_NB);
     }

@@ -39,7 +39,10 @@ struct VoxArgs {
     int n_host[4]; int use_n_host;                     // host-known segment lengths (raw map), else dyn[].n
     const int* n_dev[4];                               // producer's device counters (scan grids), else dyn[].n
     int bin_pts, bin_max;                              // binned path: aim at bin_pts points per bin, at most bin_max bins
-    const unsigned* binCountCached;                    // [nseg][VB_NB] per-bin point counts of an UNCHANGED input (bbox_cached plans): vb_hist is skipped
+    const unsigned* binCountCached;                    // [nseg][VB_NB] per-bin point counts from vb_colscan (plans with a deterministic partition): vb_hist is skipped
+    unsigned* binCountOut;                             // … where vb_colscan writes them
+    int* planMiss;                                     // [nseg] vb_plan: a point outside the previous run's grid
+    int plan_spec;                                     // this run takes bbox and per-bin counts in one pass (vb_plan); vox_setup validates the counts
     unsigned* wprefix;                                 // [nseg][VB_WG][VB_NB] points of bin b in the ranges of workgroups < w (deterministic partition)
 };
 
@@ -180,6 +183,10 @@ __global__ __launch_bounds__(64) void vox_setup_kernel(Batch<VoxArgs> B_)
     const int s = blockIdx.x;                     // one wavefront per segment
     VoxGrid& g = a.grid[s];
     if (threadIdx.x == 0) a.d_n[s] = seg_len(a, s);                  // (also written by vox_minmax; a batch with a cached bbox skips that pass)
+    // the geometry the previous run left (vb_plan took its histogram under it)
+    const int o_min0 = g.min_b[0], o_min1 = g.min_b[1], o_min2 = g.min_b[2], o_div0 = g.div_b[0], o_div1 = g.div_b[1], o_div2 = g.div_b[2];
+    const int o_shift = g.bin_shift, o_nbins = g.nbins, o_over = g.overflow;
+    const float o_inv = g.inv;
     {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         float ilo = INFINITY, ihi = -INFINITY;
@@ -218,6 +225,8 @@ __global__ __launch_bounds__(64) void vox_setup_kernel(Batch<VoxArgs> B_)
             ilo = ihi = 0.f;
         }
         vox_setup_math(g, a.st[s].leaf, a.seg_cap, ilo, ihi, a.bin_pts, a.bin_max);
+        g.plan_ok = (a.plan_spec && a.planMiss[s] == 0 && !o_over && !g.overflow && o_nbins > 0 && o_nbins == g.nbins && o_shift == g.bin_shift && o_inv == g.inv &&
+                     o_min0 == g.min_b[0] && o_min1 == g.min_b[1] && o_min2 == g.min_b[2] && o_div0 == g.div_b[0] && o_div1 == g.div_b[1] && o_div2 == g.div_b[2]) ? 1 : 0;
     }
     a.d_nbits[s] = g.nbits;
     if (a.h_ncells) a.h_ncells[s] = g.ncells;                        // pinned host: AUTO's hint for the next batch
@@ -497,12 +506,104 @@ __global__ __launch_bounds__(256) void vb_hist_kernel(Batch<VoxArgs> B_)
 // shared only at the piece ends — with no global atomics at all.
 __device__ __forceinline__ int vb_wg_points(int n) { const int k = (n + VB_STILE * VB_WG - 1) / (VB_STILE * VB_WG); return VB_STILE * max(k, 1); }
 
+// The reference runs getMinMax3D and then bins every point, for every scan (VoxelGrid::applyFilter, mapOptimization.cpp:958-965).
+// Here both happen in ONE pass over the raw map: workgroup w takes the bbox partial record of its contiguous range and, in the
+// same sweep, the per-bin counts of that range under the grid geometry the PREVIOUS run of this plan left in a.grid[s] — the
+// same geometry whenever the map's extent did not move by a voxel, which vox_setup verifies against the bbox found here
+// (g.plan_ok); a point outside that grid, or a changed grid, sends the counts through vb_hist_w once more.
+__global__ __launch_bounds__(256) void vb_plan_kernel(Batch<VoxArgs> B_)
+{
+    const VoxArgs& a = B_.a[blockIdx.z];
+    const int s = blockIdx.y, w = blockIdx.x;
+    const int n = seg_len(a, s);
+    if (w == 0 && threadIdx.x == 0) { a.d_n[s] = n; }
+    const VoxGrid& g = a.grid[s];
+    __shared__ unsigned cnt[VB_NB];
+    __shared__ int smiss;
+    const bool spec = g.n_valid > 0 && !g.overflow && g.nbins > 0 && g.nbins <= VB_NB;
+    const int nbins = spec ? g.nbins : 0, sh = g.bin_shift;
+    const int d0 = g.div_b[0], d1 = g.div_b[1], d2 = g.div_b[2];
+    for (int b = threadIdx.x; b < nbins; b += 256) cnt[b] = 0u;
+    if (threadIdx.x == 0) smiss = spec ? 0 : 1;
+    __syncthreads();
+    const int K = vb_wg_points(n);
+    const int i0 = min(n, w * K), i1 = min(n, i0 + K);
+    const int off = a.dyn[s].in_off;
+    const lvi_pt* __restrict__ in = a.st[s].in + off;
+    const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float imn = INFINITY, imx = -INFINITY;
+    int c = 0, miss = 0;
+    for (int base = i0; base < i1; base += VB_STILE) {
+        for (int u0 = 0; u0 < VB_STILE / 256; u0 += 8) {
+            lvi_pt p[8]; bool keep[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = base + (u0 + u) * 256 + threadIdx.x, ic = max(min(i, i1 - 1), 0);
+                keep[u] = i < i1 && (!mask || mask[ic]);
+                p[u] = in[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (!keep[u]) continue;
+                mn[0] = fminf(mn[0], p[u].x); mn[1] = fminf(mn[1], p[u].y); mn[2] = fminf(mn[2], p[u].z);
+                mx[0] = fmaxf(mx[0], p[u].x); mx[1] = fmaxf(mx[1], p[u].y); mx[2] = fmaxf(mx[2], p[u].z);
+                imn = fminf(imn, p[u].intensity); imx = fmaxf(imx, p[u].intensity);
+                c++;
+                if (spec) {
+                    const int ijk0 = (int)sub_rn(floorf(mul_rn(p[u].x, g.inv)), (float)g.min_b[0]);
+                    const int ijk1 = (int)sub_rn(floorf(mul_rn(p[u].y, g.inv)), (float)g.min_b[1]);
+                    const int ijk2 = (int)sub_rn(floorf(mul_rn(p[u].z, g.inv)), (float)g.min_b[2]);
+                    if ((unsigned)ijk0 < (unsigned)d0 && (unsigned)ijk1 < (unsigned)d1 && (unsigned)ijk2 < (unsigned)d2)
+                        atomicAdd(&cnt[((unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2) >> sh], 1u);
+                    else miss = 1;
+                }
+            }
+        }
+    }
+    // bbox partial record of this workgroup (vox_setup folds the records; those of ranges beyond the input stay empty)
+    __shared__ float smn[4][4], smx[4][4];
+    __shared__ int scnt[4];
+    c = wave_sum(c);
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    imn = wave_min(imn); imx = wave_max(imx);
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) { smn[wave_id()][d] = mn[d]; smx[wave_id()][d] = mx[d]; }
+        smn[wave_id()][3] = imn; smx[wave_id()][3] = imx;
+        scnt[wave_id()] = c;
+    }
+    if (miss) smiss = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int cc = 0;
+        float lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int q = 0; q < 4; q++) {
+            cc += scnt[q];
+#pragma unroll
+            for (int d = 0; d < 4; d++) { lo[d] = fminf(lo[d], smn[q][d]); hi[d] = fmaxf(hi[d], smx[q][d]); }
+        }
+        if (w < a.nblk_mm) {                        // (a range that holds points always has w < nblk_mm)
+            float* rec = a.mmPartial + ((size_t)s * a.nblk_mm + w) * 12;
+            rec[0] = lo[0]; rec[1] = lo[1]; rec[2] = lo[2]; rec[3] = hi[0]; rec[4] = hi[1]; rec[5] = hi[2];
+            rec[6] = __int_as_float(cc); rec[7] = lo[3]; rec[8] = hi[3];
+        }
+        if (w + VB_WG < a.nblk_mm) (a.mmPartial + ((size_t)s * a.nblk_mm + w + VB_WG) * 12)[6] = __int_as_float(0);   // records another realisation's bbox pass may have left
+        if (smiss && i0 < i1) atomicOr(&a.planMiss[s], 1);
+        if (!spec && w == 0) atomicOr(&a.planMiss[s], 1);
+    }
+    unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_NB;
+    for (int b = threadIdx.x; b < nbins; b += 256) row[b] = cnt[b];
+}
+
 __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
 {
     const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y, w = blockIdx.x;
     const int n = a.d_n[s];
     const VoxGrid& g = a.grid[s];
+    if (a.plan_spec && g.plan_ok) return;           // vb_plan's counts stand
     __shared__ unsigned cnt[VB_NB];
     const int nbins = g.nbins, sh = g.bin_shift;
     for (int b = threadIdx.x; b < nbins; b += 256) cnt[b] = 0u;
@@ -531,9 +632,10 @@ __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
 }
 
 // per bin: exclusive prefix over the workgroups (in place) and the bin's total
-__global__ __launch_bounds__(256) void vb_colscan_kernel(Batch<VoxArgs> B_, unsigned* totals)
+__global__ __launch_bounds__(256) void vb_colscan_kernel(Batch<VoxArgs> B_)
 {
-    const VoxArgs& a = B_.a[0];
+    const VoxArgs& a = B_.a[blockIdx.z];
+    unsigned* totals = a.binCountOut;
     const int s = blockIdx.y;
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= VB_NB) return;
@@ -549,6 +651,7 @@ __global__ __launch_bounds__(256) void vb_colscan_kernel(Batch<VoxArgs> B_, unsi
         }
     }
     totals[(size_t)s * VB_NB + b] = acc;
+    if (b == 0 && a.plan_spec) a.planMiss[s] = 0;      // consumed (vox_setup read it): the next run's vb_plan starts clean
 }
 
 __global__ __launch_bounds__(256) void vb_scatter_det_kernel(Batch<VoxArgs> B_)
@@ -1068,7 +1171,7 @@ static VoxArgs make_args(const VoxelPlan& p)
                    p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
                    p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_lightBin, p.d_multiOwner, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
                    {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0,
-                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max, (p.bbox_cached && p.hist_cached) ? p.d_binCountCached : nullptr, p.d_wprefix};
+                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max, ((p.plan_per_run && p.d_wprefix) || (p.bbox_cached && p.hist_cached)) ? p.d_binCountCached : nullptr, p.d_binCountCached, p.d_planMiss, (p.plan_per_run && p.d_wprefix) ? 1 : 0, p.d_wprefix};
 }
 
 void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs)
@@ -1361,7 +1464,7 @@ void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& p, const char* tag, double
     if (voxel_resolve_mode(p) == VOX_BINNED && p.d_binCountCached) {
         LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, 1), dim3(64), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[2], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_w_kernel, dim3(VB_WG, p.nseg, 1), dim3(256), 0, ctx.stream, B));
-        hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 256, p.nseg), dim3(256), 0, ctx.stream, B, p.d_binCountCached);
+        hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 256, p.nseg, 1), dim3(256), 0, ctx.stream, B);
         LVI_HIP(hipGetLastError());
         p.hist_cached = true;
     }
@@ -1413,10 +1516,19 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
     for (int i = 0; i < 15; i++) snprintf(nm[i], sizeof(nm[i]), "%s/%s", base[i], tag);
     // the bbox pass is skipped when every plan of the batch holds the partial records of its (unchanged) input: the raw
     // local map gets them where its points are touched anyway — upload / assembly — instead of once per re-voxelisation
-    bool cached = true;
-    for (int z = 0; z < S; z++) cached = cached && plans[z]->bbox_cached;
-    if (!cached) LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, S), dim3(256), 0, ctx.stream, B));
-    LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, S), dim3(64), 0, ctx.stream, B));
+    bool cached = true, per_run = mode == VOX_BINNED;
+    for (int z = 0; z < S; z++) { cached = cached && plans[z]->bbox_cached; per_run = per_run && B.a[z].plan_spec != 0; }
+    if (per_run) {
+        // reference-faithful raw map: bbox + per-bin counts inside this run, one pass (vb_plan), validated by vox_setup
+        LVI_LAUNCH(ctx, "vb_plan/map", 16.0 * n_hint, hipLaunchKernelGGL(vb_plan_kernel, dim3(VB_WG, p.nseg, S), dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, S), dim3(64), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, "vb_hist_w/map", 0, hipLaunchKernelGGL(vb_hist_w_kernel, dim3(VB_WG, p.nseg, S), dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, "vb_colscan/map", 0, hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 256, p.nseg, S), dim3(256), 0, ctx.stream, B));
+    } else {
+        for (int z = 0; z < S; z++) B.a[z].plan_spec = 0;
+        if (!cached) LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, S), dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, S), dim3(64), 0, ctx.stream, B));
+    }
     if (mode == VOX_BINNED) {
         const dim3 gt(div_up(p.seg_cap, VB_STILE), p.nseg, S);
         const dim3 gb(std::max(64, std::min(div_up(p.seg_cap, 2048), VB_ACC_BLOCKS)), p.nseg, S);       // grid-stride over the bins

@@ -35,6 +35,7 @@ struct VoxGrid {                 // device, per segment
     // ---- binned path: bin = idx >> bin_shift, nbins <= VB_NB
     int bin_shift, nbins;
     unsigned long long ncells;   // div_b product (0 when the overflow rule fired or the segment is empty)
+    int plan_ok;                 // vb_plan's histogram (taken under the PREVIOUS run's geometry, in the pass that takes the bbox) is valid for this run's geometry
 };
 
 constexpr int VOX_HT = 1024;     // keys per workgroup in the head (segment boundary) kernels
@@ -93,6 +94,9 @@ struct VoxelPlan {
     unsigned* d_wprefix = nullptr;            // [nseg][VB_WG][VB_NB] per-(workgroup, bin) prefix of the deterministic partition, plans that cache only
     unsigned* d_binCountCached = nullptr;     // [nseg][VB_NB] points per bin of the current input (voxel_bbox_pass), plans that cache only
     mutable bool hist_cached = false;         // … valid (binned realisation was the resolved one when the pass ran)
+    bool plan_per_run = false;                // the raw local map in its reference-faithful form: bbox and per-bin counts are taken inside EVERY run (vb_plan: one
+                                              // pass for both, the histogram under the previous run's grid geometry, re-taken by vb_hist_w when the geometry moved)
+    int* d_planMiss = nullptr;                // [nseg] a point fell outside the previous geometry (vb_plan)
     bool bbox_cached = false;                 // d_mmPartial holds the bbox partials of the CURRENT input (voxel_bbox_pass ran after the input was written)
 
     template <class AR> void allocate(AR& ar, int nseg_, int seg_cap_, bool concat)
@@ -127,6 +131,7 @@ struct VoxelPlan {
         d_multiOwner = ar.template alloc<int>((size_t)nseg_ * max_multi);
         d_chunkTabV = ar.template alloc<unsigned long long>((size_t)nseg_ * max_multi * (4 * VB_TAB));
         d_chunkTabC = ar.template alloc<unsigned>((size_t)nseg_ * max_multi * VB_TABC);
+        d_planMiss = ar.template alloc<int>(nseg_);
     }
     void release();                                                            // frees h_ncells
     void set_static(const Ctx& ctx, const VoxSegStatic* host_segs);           // H2D of the per-segment pointers (+ the pinned hint)

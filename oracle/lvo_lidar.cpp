@@ -763,7 +763,7 @@ void lvi_lidar_params_default(lvi_lidar_params* p)
     p->icp_max_iters = 20; p->icp_disable_break = 0;
     p->max_raw_points = 131072; p->max_map_points = 1 << 20; p->voxel_mode = 0;
     p->max_keyframes = 1024; p->max_keyframe_points = 1 << 22; p->map_on_main_stream = 0;
-    p->sector_handover_wait_us = 0; p->batch_scans = 1;
+    p->sector_handover_wait_us = 0; p->batch_scans = 1; p->map_plan_cache = 0;
 }
 
 int32_t lvi_lidar_create(const lvi_lidar_params* p, int32_t /*device*/, lvi_lidar** out)

@@ -25,7 +25,7 @@ def test_hip_library_exports_every_symbol(pkg):
         assert hasattr(dll, name), f"{name} missing from liblvi_hip.so"
     lib = pkg.load_hip()
     assert lib.backend == "hip-gfx950"
-    assert lib.dll.lvi_abi_version() == 5
+    assert lib.dll.lvi_abi_version() == 6
 
 
 def test_oracle_exports_every_symbol(pkg, oracle):
@@ -36,7 +36,7 @@ def test_oracle_exports_every_symbol(pkg, oracle):
 
 def test_struct_sizes(pkg):
     A = pkg._abi
-    assert ctypes.sizeof(A.LidarParams) == 104
+    assert ctypes.sizeof(A.LidarParams) == 108
     assert ctypes.sizeof(A.IcpResult) == 6 * 4 + 64 * 4 + 24
     assert ctypes.sizeof(A.KernelStat) == 48 + 8 + 8 + 8
     assert A.PT_DTYPE.itemsize == 16 and A.LIVOX_DTYPE.itemsize == 20

@@ -1005,3 +1005,121 @@ def test_corner_eigenvalue_ratio_gate(pkg, oracle, hip):
     clear = np.abs(ratios - 3.0) > 0.02
     np.testing.assert_array_equal(flags[1][clear], np.array(expect)[clear])
     o.close(); g.close()
+
+
+# ----------------------------------------------------------------------------- round 3: map plan per rebuild, advisor regressions
+def _map_ds_bits(g):
+    return [xyzi(c).view(np.uint32).copy() for c in g.get_map_ds()]
+
+
+def test_map_plan_per_rebuild_matches_cached_plan(pkg, hip, scene):
+    """lvi_lidar_params.map_plan_cache: 0 (default) takes the bounding box and the per-bin counts inside EVERY re-voxelisation
+    of the raw map (one pass, the counts under the previous run's grid geometry, re-taken when the geometry moved); 1 takes them
+    once per upload.  Same DS map bits either way, for an unchanged map, a map that moved by half a metre (same size, other
+    grid), a smaller map, and back; batch slots included."""
+    mc, ms = scene["map_corner"], scene["map_surf"]
+    sh_c, sh_s = mc.copy(), ms.copy()
+    sh_c["x"] += 0.5; sh_s["x"] += 0.5; sh_c["z"] -= 0.7; sh_s["z"] -= 0.7
+    maps = [(mc, ms), (mc, ms), (sh_c, sh_s), (mc[: len(mc) // 2], ms[: len(ms) // 3]), (mc, ms)]
+    per, cached = pkg.LidarHotpath(hip, **small_params(voxel_mode=2)), pkg.LidarHotpath(hip, **small_params(voxel_mode=2, map_plan_cache=1))
+    auto = pkg.LidarHotpath(hip, **small_params())                 # AUTO: first build sorted, then binned with the per-run plan
+    for step, (c, s) in enumerate(maps):
+        fresh = pkg.LidarHotpath(hip, **small_params(voxel_mode=1))
+        fresh.map_set(c, s)
+        want = _map_ds_bits(fresh)
+        fresh.close()
+        for g in (per, cached, auto):
+            if step != 1:
+                g.map_upload(c, s)
+            g.map_build()                                           # step 1: a second build of the unchanged map (plan_ok path)
+            for x, y in zip(_map_ds_bits(g), want):
+                np.testing.assert_array_equal(x, y)
+    per.close(); cached.close(); auto.close()
+    # batch slots: every slot takes its own plan
+    b = pkg.LidarHotpath(hip, **small_params(batch_scans=3, voxel_mode=2))
+    ref = pkg.LidarHotpath(hip, **small_params(voxel_mode=1))
+    for (c, s) in (maps[0], maps[2]):
+        ref.map_set(c, s); want = _map_ds_bits(ref)
+        b.map_upload(c, s); b.map_build(); b.map_build()
+        for z in range(3):
+            b.batch_select(z)
+            for x, y in zip(_map_ds_bits(b), want):
+                np.testing.assert_array_equal(x, y)
+        b.batch_select(0)
+    b.close(); ref.close()
+
+
+@pytest.mark.parametrize("cache", [0, 1], ids=["plan_per_rebuild", "plan_cached"])
+def test_replay_graph_does_not_survive_a_map_upload(pkg, hip, scene, cache):
+    """advisor, round 2: a captured launch sequence (lvi_scan_replay_enqueue) froze whether the map plan passes are part of it;
+    a re-upload of a DIFFERENT map of the same size must not replay it: the bits of a fresh handle"""
+    import torch
+    S = pkg.synth
+    P = small_params(icp_max_iters=6, icp_disable_break=1, map_plan_cache=cache)
+    pose = S.loop_pose(0.37, 0.01, -0.02)
+    scan = S.make_scan(20001, pose, 61)
+    guess = S.perturbed_guess(pose, 6)
+    d_scan = torch.from_numpy(scan.view(np.uint8).copy()).to("cuda")
+    d_rec = torch.zeros(8, dtype=torch.float32, device="cuda")
+    mc, ms = scene["map_corner"], scene["map_surf"]
+    sh_c, sh_s = mc.copy(), ms.copy()
+    sh_c["y"] += 0.9; sh_s["y"] += 0.9
+    d_c = torch.from_numpy(xyzi(sh_c).copy()).to("cuda"); d_s = torch.from_numpy(xyzi(sh_s).copy()).to("cuda")
+
+    def run(h):
+        h.scan_replay_enqueue(d_scan.data_ptr(), len(scan), guess, d_rec.data_ptr(), True); h.sync()
+        return bits(d_rec.cpu().numpy()[:6]).copy(), _map_ds_bits(h)
+
+    g = pkg.LidarHotpath(hip, **P)
+    g.map_set(mc, ms)                                               # eager build: with cache = 1 the plan is cached now
+    run(g); run(g)                                                  # captured without the plan passes (cache = 1), replayed once
+    g.map_upload_device(d_c.data_ptr(), len(sh_c), d_s.data_ptr(), len(sh_s))
+    got = run(g)
+    f = pkg.LidarHotpath(hip, **P)
+    f.map_upload(sh_c, sh_s)
+    want = run(f)
+    np.testing.assert_array_equal(got[0], want[0])
+    for x, y in zip(got[1], want[1]):
+        np.testing.assert_array_equal(x, y)
+    g.close(); f.close()
+
+
+def test_bound_scan_buffer_is_dropped_by_a_single_scan_upload(pkg, hip, scene):
+    """advisor, round 2: lvi_scan_batch_bind_device leaves the slot reading the caller's buffer; a later single-scan upload on
+    that slot must process the NEW scan"""
+    S = pkg.synth
+    a = S.make_scan(15001, S.loop_pose(0.4, 0.0, 0.0), 70)
+    b = S.make_scan(12001, S.loop_pose(1.1, 0.01, 0.0), 71)
+    rt, ptrs = _dev_buffers([a])
+    h = pkg.LidarHotpath(hip, **small_params(batch_scans=2))
+    h.batch_bind_device([ptrs[0].value], [len(a)])
+    h.scan_upload(b)                                                # slot 0, the single-scan entry point
+    h.scan_organize()
+    got = h.get_scan_info()
+    p = pkg.LidarHotpath(hip, **small_params())
+    p.scan_upload(b); p.scan_organize()
+    _assert_info_equal(got, p.get_scan_info())
+    rt.hipFree(ptrs[0])
+    h.close(); p.close()
+
+
+def test_map_owner_destroyed_before_its_sharers(pkg, hip, scene):
+    """advisor, round 2: destroying the owner of a shared raw map sends the sharers back to their own (empty) memory instead of
+    leaving them with dangling pointers; a handle that is shared cannot itself share another one's map"""
+    owner = pkg.LidarHotpath(hip, **small_params())
+    owner.map_set(scene["map_corner"], scene["map_surf"])
+    s1 = pkg.LidarHotpath(hip, **small_params()); s2 = pkg.LidarHotpath(hip, **small_params(batch_scans=2))
+    s1.map_share(owner); s1.map_build(); s2.map_share(owner); s2.map_build()
+    other = pkg.LidarHotpath(hip, **small_params())
+    other.map_set(scene["map_corner"], scene["map_surf"])
+    with pytest.raises(pkg.LviError):
+        owner.map_share(other)                                      # owner is shared: it cannot become a sharer
+    with pytest.raises(pkg.LviError):
+        owner.map_update(np.zeros(0, np.int32))                     # … nor drop its raw map
+    owner.close()                                                   # the sharers are detached here
+    with pytest.raises(pkg.LviError):
+        s1.map_build()                                              # no raw map any more: a clean error, not a fault
+    s1.map_set(scene["map_corner"], scene["map_surf"])              # and the handle works on with a map of its own
+    assert s1.counts()["map_surf_ds"] == other.counts()["map_surf_ds"]
+    s2.map_share(other); s2.map_build()
+    s1.close(); s2.close(); other.close()
