@@ -207,10 +207,18 @@ __device__ __forceinline__ void knn_insert(KnnKeys& r, unsigned long long key)
 // the true fifth-nearest distance cannot exceed it and the scan shrinks from the unit ball to a ~0.4 m one (exact: every
 // cell the smaller ball reaches is still scanned, ties included since the test is <=).
 constexpr float KNN_R2_FULL = 0x1.fffffep-1f;
-template <int G, int KNN_KB>
-__device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
-                                                  float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr, float r2max = KNN_R2_FULL,
-                                                  bool want_lb = false, float* lb2 = nullptr)
+// Where a search reads the index from: straight from global memory (L2), or from the wavefront's LDS tile (below).
+// start(ok, y, z, x): position, in the accessor's point array, of the first point of cell (x, y, z) — x may be one past the
+// row's last cell; pt(i): point i of that array (xyz + map index in the intensity slot).
+struct KnnDirect {
+    const int* __restrict__ cs; const lvi_pt* __restrict__ pts; int dimx, dimy;
+    __device__ __forceinline__ int start(bool ok, int y, int z, int x) const { return cs[ok ? (z * dimy + y) * dimx + x : 0]; }
+    __device__ __forceinline__ lvi_pt pt(int i) const { return pts[i]; }
+};
+template <int G, int KNN_KB, class ACC>
+__device__ __forceinline__ void knn5_search_acc(const GridIndex::Meta& m, const ACC& acc, bool act,
+                                                float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr, float r2max = KNN_R2_FULL,
+                                                bool want_lb = false, float* lb2 = nullptr)
 {
     constexpr int KNN_RPL = (25 + G - 1) / G;         // rows per lane
 #define LVI_KT(slot) do { if (tk) tk[slot] = clock64(); } while (0)
@@ -219,7 +227,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
 #pragma unroll
     for (int k = 0; k < 5; k++) r.k[k] = KNN_EMPTY;
     unsigned rej = 0x7F800000u;                       // smallest squared distance (float bits) among the candidates that lose their place
-    if (m.ok && m.n > 0) {
+    if (m.ok && m.n > 0) {                            // (wave-uniform)
         const float e = (float)m.edge, inv_e = (float)m.inv_edge;
         // cell of the query (double, as cell_of) and its position inside that cell in [0,1) (f32 is plenty: the row
         // tests below only have to be conservative, and they carry a 1e-4 margin)
@@ -256,7 +264,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 const int rq = (rr * inv_ny) >> 8;
                 const int dy = y0 + rr - rq * ny, dz = z0 + rq;
                 const int y = cy + dy, z = cz + dz;
-                bool ok = rr < nrows && y >= 0 && y < m.dim[1] && z >= 0 && z < m.dim[2];
+                bool ok = act && rr < nrows && y >= 0 && y < m.dim[1] && z >= 0 && z < m.dim[2];
                 // distance (m) from the query to the row's slab along y and z; 0 inside
                 const float ddy = dy == 0 ? 0.f : (dy > 0 ? (float)dy - ty : ty - (float)(dy + 1)) * e;
                 const float ddz = dz == 0 ? 0.f : (dz > 0 ? (float)dz - tz : tz - (float)(dz + 1)) * e;
@@ -266,9 +274,8 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 const float sx = sqrtf(fmaxf(rem, 0.f)) * inv_e + 1e-4f;
                 const int x0 = max(cx + (int)floorf(tx - sx), 0), x1 = min(cx + (int)floorf(tx + sx), m.dim[0] - 1);
                 ok = ok && x0 <= x1;
-                const int row = ok ? (z * m.dim[1] + y) * m.dim[0] : 0;
-                rbv[t] = cell_start[row + (ok ? x0 : 0)];          // consumed after the loop: nothing in here waits for a load
-                rev[t] = cell_start[row + (ok ? x1 : 0) + 1];
+                rbv[t] = acc.start(ok, y, z, x0);                   // consumed after the loop: nothing in here waits for a load
+                rev[t] = acc.start(ok, y, z, x1 + 1);
                 okv[t] = ok;
             }
         }
@@ -287,7 +294,7 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
                 int o = off[0];
 #pragma unroll
                 for (int t = 1; t < KNN_RPL; t++) o = f >= st[t] ? off[t] : o;
-                p[u] = sorted[f < T ? f + o : 0];               // unconditional (entry 0 when past the list: masked below): the batch's loads travel together
+                p[u] = acc.pt(f < T ? f + o : 0);               // unconditional (entry 0 when past the list: masked below): the batch's loads travel together
             }
             LVI_KT(2);
 #pragma unroll
@@ -323,6 +330,124 @@ __device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, cons
         for (int o = G / 2; o > 0; o >>= 1) { const unsigned v = __shfl_xor(rej, o, 64); rej = v < rej ? v : rej; }
         *lb2 = fminf(__uint_as_float(rej), r2max);
     }
+}
+
+template <int G, int KNN_KB>
+__device__ __forceinline__ void knn5_search_group(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
+                                                  float qx, float qy, float qz, int sub, Knn5& out, long long* tk = nullptr, float r2max = KNN_R2_FULL,
+                                                  bool want_lb = false, float* lb2 = nullptr)
+{
+    const KnnDirect acc{cell_start, sorted, m.dim[0], m.dim[1]};
+    knn5_search_acc<G, KNN_KB>(m, acc, true, qx, qy, qz, sub, out, tk, r2max, want_lb, lb2);
+}
+
+// ---- LDS-staged candidate tiles.  One wavefront searches for 64 / G features that follow each other in the scan's voxel order:
+// their balls overlap or lie next to each other, so the wavefront first copies the part of the index all of them can reach —
+// the bounding box, in cells, of their search regions: the cell starts of its rows and the points of those rows — into ITS
+// region of LDS: two rounds of loads with every lane busy, instead of one dependent round per batch of four candidates and
+// lane.  The searches then run on the tile with the same row geometry, hence the same candidates and the same five.  A tile
+// that does not fit (features far apart, a dense corner of the map) sends the wavefront down the direct path: same result.
+template <int TP, int TC>
+struct KnnTile { int cs[TC]; int toff[65]; float4 pt[TP]; };
+template <int TP, int TC>
+struct KnnTileAcc {
+    const KnnTile<TP, TC>* T; int X0, Y0, Z0, nx1, ny;
+    __device__ __forceinline__ int start(bool ok, int y, int z, int x) const
+    {
+        const int r = ok ? (z - Z0) * ny + (y - Y0) : 0;
+        const int base = r * nx1;
+        return T->cs[base + (ok ? x - X0 : 0)] - T->cs[base] + T->toff[r];
+    }
+    __device__ __forceinline__ lvi_pt pt(int i) const { const float4 v = T->pt[i]; return lvi_pt{v.x, v.y, v.z, v.w}; }
+};
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v; }
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v; }
+__device__ __forceinline__ void wave_lds_fence() { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+
+// every lane of the wavefront calls this (act: the lane's feature searches).  true: the tile is built and `acc` reads it.
+template <int TP, int TC>
+__device__ __forceinline__ bool knn_tile_build(const GridIndex::Meta& m, const int* __restrict__ cell_start, const lvi_pt* __restrict__ sorted,
+                                               bool act, float qx, float qy, float qz, float r2max, KnnTile<TP, TC>& T, KnnTileAcc<TP, TC>& acc)
+{
+    if (!(m.ok && m.n > 0)) return false;
+    const int lane = lane_id();
+    const float inv_e = (float)m.inv_edge;
+    // the cells this lane's search can touch (a superset of the rows / x-ranges knn5_search_acc derives from the same values)
+    const double gx = ((double)qx - m.origin[0]) * m.inv_edge, gy = ((double)qy - m.origin[1]) * m.inv_edge, gz = ((double)qz - m.origin[2]) * m.inv_edge;
+    const double fxd = floor(gx), fyd = floor(gy), fzd = floor(gz);
+    const float tx = (float)(gx - fxd), ty = (float)(gy - fyd), tz = (float)(gz - fzd);
+    const int cx = (int)fmin(fmax(fxd, -4.0), (double)m.dim[0] + 4.0), cy = (int)fmin(fmax(fyd, -4.0), (double)m.dim[1] + 4.0),
+              cz = (int)fmin(fmax(fzd, -4.0), (double)m.dim[2] + 4.0);
+    const float rc = sqrtf(r2max + 1e-4f) * inv_e + 2e-4f;
+    int xa = max(cx + (int)floorf(tx - rc), 0), xb = min(cx + (int)floorf(tx + rc), m.dim[0] - 1);
+    int ya = max(cy + max((int)floorf(ty - rc), -m.R), 0), yb = min(cy + min((int)floorf(ty + rc), m.R), m.dim[1] - 1);
+    int za = max(cz + max((int)floorf(tz - rc), -m.R), 0), zb = min(cz + min((int)floorf(tz + rc), m.R), m.dim[2] - 1);
+    const bool any = act && xa <= xb && ya <= yb && za <= zb;
+    const int BIG = 0x3fffffff;
+    const int X0 = wave_min_i(any ? xa : BIG), X1 = wave_max_i(any ? xb : -BIG);
+    const int Y0 = wave_min_i(any ? ya : BIG), Y1 = wave_max_i(any ? yb : -BIG);
+    const int Z0 = wave_min_i(any ? za : BIG), Z1 = wave_max_i(any ? zb : -BIG);
+    acc.T = &T; acc.X0 = X0; acc.Y0 = Y0; acc.Z0 = Z0; acc.nx1 = 1; acc.ny = 1;
+    if (X0 > X1) {                                   // nothing to search in reach of the grid: an empty tile serves every lane
+        if (lane == 0) { T.cs[0] = 0; T.toff[0] = 0; }
+        wave_lds_fence();
+        return true;
+    }
+    const long long nxl = (long long)X1 - X0 + 2, nyl = (long long)Y1 - Y0 + 1, nzl = (long long)Z1 - Z0 + 1;
+    if (nyl * nzl > 64 || nxl * nyl * nzl > TC) return false;
+    const int nx1 = (int)nxl, ny = (int)nyl, nrows = (int)(nyl * nzl), ncs = nx1 * nrows;
+    acc.nx1 = nx1; acc.ny = ny;
+    // round 1: the cell starts of the tile's rows, every lane a share, all loads in flight together
+    {
+        constexpr int NL = (TC + 63) / 64;
+        int v[NL];
+        const float rcp = 1.0f / (float)nx1;
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int e = lane + 64 * k, ec = min(e, ncs - 1);
+            int r = (int)((float)ec * rcp);
+            r -= (r * nx1 > ec) ? 1 : 0; r += ((r + 1) * nx1 <= ec) ? 1 : 0;
+            const int ix = ec - r * nx1;
+            const int y = Y0 + r % ny, z = Z0 + r / ny;
+            v[k] = (k * 64 < ncs) ? cell_start[(z * m.dim[1] + y) * m.dim[0] + X0 + ix] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) { const int e = lane + 64 * k; if (e < ncs) T.cs[e] = v[k]; }
+    }
+    wave_lds_fence();
+    // the rows' lengths -> where each row's points sit in the tile
+    const int len = lane < nrows ? T.cs[lane * nx1 + nx1 - 1] - T.cs[lane * nx1] : 0;
+    const int incl = wave_incl_scan(len);
+    const int P = __shfl(incl, 63, 64);
+    if (P > TP) return false;
+    if (lane < nrows) T.toff[lane] = incl - len;
+    if (lane == 0) T.toff[nrows] = P;
+    wave_lds_fence();
+    // round 2: the points
+    {
+        constexpr int NL = (TP + 63) / 64;
+        lvi_pt v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = lane + 64 * k, ic = min(i, max(P - 1, 0));
+            // the row of tile position ic: the last r with toff[r] <= ic (rows are few: a 6-step search in LDS)
+            int lo = 0, hi = nrows;                  // toff[lo] <= ic < toff[hi]
+#pragma unroll
+            for (int it = 0; it < 6; it++) { const int mid = (lo + hi) >> 1; const bool up = mid < hi && T.toff[mid] <= ic; lo = up ? mid : lo; hi = up ? hi : mid; }
+            const int src = T.cs[lo * nx1] + (ic - T.toff[lo]);
+            v[k] = sorted[(k * 64 < P) ? src : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) { const int i = lane + 64 * k; if (i < P) T.pt[i] = make_float4(v[k].x, v[k].y, v[k].z, v[k].intensity); }
+    }
+    wave_lds_fence();
+    return true;
 }
 
 __global__ __launch_bounds__(256) void knn_debug_kernel(const GridIndex::Meta* meta, const int* cell_start, const lvi_pt* sorted,
@@ -489,6 +614,8 @@ struct IcpArgs {
     float4* fit2;                                 // [cap] corner: the second line point
     unsigned char* fit_ok;                        // [cap] 0: no fit stored; 1: stored, geometric gate passed; 2: stored, gate failed
     float knn_slack;                              // metres added to the radius of a bounded search (room for later iterations to skip theirs)
+    int lds_tiles;                                // LVI_KNN_TILES=1: phase A stages the index tile of a wavefront's features in LDS when it fits (4 lanes per feature; same bits; see DESIGN for why it is not the default)
+    int stamp_iter;                               // the iteration whose phase stamps are kept in cyc[] (LVI_ICP_STAMP_ITER, default: the last one launched)
     int xcd_map;                                  // residual workgroups are dealt to the XCDs in contiguous feature ranges (LVI_ICP_NO_XCD_MAP=1: in launch order)
     // normal equations: 28 columns x {coarse, fine} exact fixed-point accumulators, ICP_SHARDS shards (workgroup & 7), three
     // buffers in rotation: launch i adds into buffer i % 3, reads the totals of launch i - 1 from (i - 1) % 3 and zeroes (i + 1) % 3
@@ -649,7 +776,7 @@ __global__ __launch_bounds__(64) void set_pose_init_kernel(Batch<PoseInitArgs> B
     make_pose(s.pose[0]);
     s.cur = 0;
     s.done = 0; s.converged = 0; s.degenerate = 0; s.iters = 0; s.any_lm = 0; s.status = LVI_OK;
-    a.cyc[15] = 0;                                 // searches counted by the Gauss-Newton kernel (debug read-out)
+    a.cyc[15] = 0; a.cyc[10] = 0; a.cyc[11] = 0;   // searches / wavefront rounds (direct, tiled) counted by the Gauss-Newton kernel (debug read-out)
     for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) s.n_sel[i] = 0;
 }
 
@@ -1006,8 +1133,8 @@ __device__ __forceinline__ void fx_split(double v, long long& coarse, long long&
 //   C  the 27 products of the rows are formed in f64 and added up in a fixed shape; the 28 sums join the launch's exact
 //      fixed-point accumulators (integer adds commute: the totals do not depend on arrival order, on the lanes per feature or
 //      on the XCD placement).  Nobody waits for the adds: the next launch reads the totals.
-template <int QPB, bool FIRST, int G, int KB>
-__global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<IcpArgs> B_, int iter)
+template <int QPB, bool FIRST, int G, int KB, bool TILES = false>
+__global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_gn_kernel(Batch<IcpArgs> B_, int iter)
 {
     constexpr int NT = QPB == 64 ? 64 * G : 256;
     static_assert(QPB == 64 || QPB == 256, "features per workgroup");
@@ -1036,7 +1163,7 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<
     const int per_xcd = (nb + 7) / 8;
     const int wg = a.xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if ((a.xcd_map && (int)(blockIdx.x >> 3) >= per_xcd) || wg >= nb) return;
-    const bool stamp = (wg == nb / 2 && threadIdx.x == 0);                         // a surf workgroup in the middle
+    const bool stamp = (wg == nb / 2 && threadIdx.x == 0 && (a.stamp_iter < 0 || a.stamp_iter == iter));      // a surf workgroup in the middle
     long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     __shared__ float sA[12], sT[6];
@@ -1044,7 +1171,7 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<
     __shared__ long long spi[QPB / 16][56];         // exact fixed-point images (coarse, fine) of the sums of 16 consecutive features
     __shared__ double ssum[28], stmp[56];
     __shared__ float spt[5][3][QPB];                // the five neighbours' coordinates, in the record's order
-    __shared__ float sd[5][QPB];                    // squared distances, ascending
+    __shared__ float sd4[QPB];                      // squared distance of the fifth nearest (the callers' gate)
     __shared__ int si[5][QPB];                      // their map indices
     __shared__ int sidr[5][QPB];                    // the record's indices (phase A compares its result with them)
     __shared__ float sori[4][QPB];
@@ -1053,6 +1180,8 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<
     __shared__ float sr2[QPB];                      // search radius (squared) of the features that search, in list order
     __shared__ unsigned short slist[QPB];           // the features (workgroup-local) that search in this iteration
     __shared__ int swcnt[QPB / 64];                 // searching features per wavefront
+    constexpr int TP = FIRST ? 384 : 256, TC = FIRST ? 1024 : 768;      // points / cell starts of a wavefront's index tile (unit ball | bounded ball)
+    __shared__ __attribute__((aligned(16))) KnnTile<TP, TC> stile[TILES ? NT / 64 : 1];      // (the tile form is a separate instantiation: LVI_KNN_TILES=1)
     __shared__ int sdone;
     const bool use_prev = !FIRST && a.nn_prev != nullptr;
     const int cap = a.cap;
@@ -1149,14 +1278,16 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 const unsigned lo = (unsigned)kk.k[j];
-                sd[j][ql] = __uint_as_float((unsigned)(kk.k[j] >> 32)); si[j][ql] = (int)(lo >> 3);
+                if (j == 4) sd4[ql] = __uint_as_float((unsigned)(kk.k[j] >> 32));
+                si[j][ql] = (int)(lo >> 3);
                 perm |= (lo & 7u) << (3 * j);
             }
             srefit[ql] = (perm != PERM_ID || fok == 0u) ? 1 : 0;
         }
         if (!active) {
 #pragma unroll
-            for (int j = 0; j < 5; j++) { sd[j][ql] = INFINITY; si[j][ql] = -1; }
+            for (int j = 0; j < 5; j++) si[j][ql] = -1;
+            sd4[ql] = INFINITY;
             srefit[ql] = 0;
         }
 #pragma unroll
@@ -1187,36 +1318,45 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<
         float r2 = KNN_R2_FULL;
         for (int base = 0; base < nsearch; base += NT / G) {
             const int gi = base + threadIdx.x / G, sub = threadIdx.x % G;
-            if (gi < nsearch) {
-                const int qs = slist[gi];
-                const int ts = wg * QPB + qs;
-                const int w = ts < nC ? 0 : 1;
-                lvi_pt o2; o2.x = sori[0][qs]; o2.y = sori[1][qs]; o2.z = sori[2][qs]; o2.intensity = 0.f;
-                const lvi_pt sel = to_map(sA, o2);
-                r2 = sr2[gi];
-                Knn5 r;
-                float lb2 = 0.f;
-                knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
-                if (sub == 0) {
-                    const bool five = r.d[4] < 1.0f;
-                    // the same five in the same order as the record (a search usually confirms them): its coordinates and its fit stand
-                    bool same = five && use_prev && sfok[qs] != 0;
+            const bool act = gi < nsearch;
+            const int qs = act ? slist[gi] : 0;
+            const int ts = wg * QPB + qs;
+            const int w = ts < nC ? 0 : 1;
+            lvi_pt o2; o2.x = sori[0][qs]; o2.y = sori[1][qs]; o2.z = sori[2][qs]; o2.intensity = 0.f;
+            const lvi_pt sel = to_map(sA, o2);
+            r2 = act ? sr2[gi] : 0.f;
+            Knn5 r;
+            float lb2 = 0.f;
+            // the wavefront's features share an LDS tile of the index when they are of one kind (corner | surf) and the tile fits
+            const unsigned long long mc = __ballot(act && w == 0), ms = __ballot(act && w == 1);
+            bool tiled = false;
+            KnnTileAcc<TP, TC> tacc;
+            const int wu = mc ? 0 : 1;
+            if (TILES && (mc == 0ull) != (ms == 0ull))
+                tiled = knn_tile_build<TP, TC>(*a.meta[wu], a.cell_start[wu], a.sorted[wu], act, sel.x, sel.y, sel.z, r2, stile[threadIdx.x >> 6], tacc);
+            if (TILES && tiled) knn5_search_acc<G, KB>(*a.meta[wu], tacc, act, sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
+            else if (act) knn5_search_group<G, KB>(*a.meta[w], a.cell_start[w], a.sorted[w], sel.x, sel.y, sel.z, sub, r, stamp ? tk : nullptr, r2, a.nn_ref != nullptr, &lb2);
+            if (TILES && (threadIdx.x & 63) == 0 && (mc | ms)) atomicAdd((unsigned long long*)&a.cyc[tiled ? 11 : 10], 1ull);   // wavefront rounds on a tile / on the direct path
+            if (act && sub == 0) {
+                const bool five = r.d[4] < 1.0f;
+                // the same five in the same order as the record (a search usually confirms them): its coordinates and its fit stand
+                bool same = five && use_prev && sfok[qs] != 0;
 #pragma unroll
-                    for (int j = 0; j < 5; j++) same = same && r.i[j] == sidr[j][qs];
-                    if (!same) {
-                        const lvi_pt* __restrict__ map = a.mapds[w];
-                        lvi_pt nbp[5];
+                for (int j = 0; j < 5; j++) same = same && r.i[j] == sidr[j][qs];
+                if (!same) {
+                    const lvi_pt* __restrict__ map = a.mapds[w];
+                    lvi_pt nbp[5];
 #pragma unroll
-                        for (int j = 0; j < 5; j++) nbp[j] = map[five ? r.i[j] : 0];           // unconditional: the five loads travel together
+                    for (int j = 0; j < 5; j++) nbp[j] = map[five ? r.i[j] : 0];           // unconditional: the five loads travel together
 #pragma unroll
-                        for (int j = 0; j < 5; j++) { spt[j][0][qs] = nbp[j].x; spt[j][1][qs] = nbp[j].y; spt[j][2][qs] = nbp[j].z; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 5; j++) { sd[j][qs] = r.d[j]; si[j][qs] = r.i[j]; }
-                    sperm[qs] = (unsigned short)PERM_ID;
-                    srefit[qs] = same ? 0 : 1;
-                    if (a.nn_ref) a.nn_ref[ts] = make_float4(sel.x, sel.y, sel.z, five ? lb2 : 0.f);
+                    for (int j = 0; j < 5; j++) { spt[j][0][qs] = nbp[j].x; spt[j][1][qs] = nbp[j].y; spt[j][2][qs] = nbp[j].z; }
                 }
+#pragma unroll
+                for (int j = 0; j < 5; j++) si[j][qs] = r.i[j];
+                sd4[qs] = r.d[4];
+                sperm[qs] = (unsigned short)PERM_ID;
+                srefit[qs] = same ? 0 : 1;
+                if (a.nn_ref) a.nn_ref[ts] = make_float4(sel.x, sel.y, sel.z, five ? lb2 : 0.f);
             }
         }
         LVI_STAMP(1);
@@ -1231,7 +1371,7 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256) void icp_gn_kernel(Batch<
         if (t < Q) {
             const bool isC = t < nC;
             const lvi_pt sel = to_map(sA, ori);
-            const bool five = sd[4][ql] < 1.0f;                                    // :1025, :1121
+            const bool five = sd4[ql] < 1.0f;                                    // :1025, :1121
             const bool refit = srefit[ql] != 0;
             const unsigned perm = sperm[ql];
             fok = sfok[ql];
@@ -1379,6 +1519,7 @@ IcpArgs icp_args(LidarDev& d)
     a.cap = d.ext_cap; a.nn_pt = d.nnPt; a.fit = d.fitA; a.fit2 = d.fitB; a.fit_ok = d.fitOk; a.acc = d.icpAcc;
     a.nn_ref = (d.knn_bound && d.knn_skip) ? d.nnRef : nullptr; a.knn_slack = d.knn_slack;
     { static const bool no_map = getenv("LVI_ICP_NO_XCD_MAP") != nullptr; a.xcd_map = no_map ? 0 : 1; }
+    a.stamp_iter = d.icp_stamp_iter; a.lds_tiles = d.knn_tiles ? 1 : 0;
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;
@@ -1644,16 +1785,19 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
             const dim3 rg((div_up(d.ext_cap, 64) + 7) & ~7, 1, S);
             if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 8, 8>), rg, dim3(512), 0, cx.stream, B, it));
             else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 2, 4>), rg, dim3(128), 0, cx.stream, B, it));
+            else if (a.lds_tiles) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 4, 4, true>), rg, dim3(256), 0, cx.stream, B, it));
             else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
         } else if (it < d.icp_wide_from) {
             const dim3 rg((div_up(d.ext_cap, 64) + 7) & ~7, 1, S);
             if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 8, 4>), rg, dim3(512), 0, cx.stream, B, it));
             else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 2, 4>), rg, dim3(128), 0, cx.stream, B, it));
+            else if (a.lds_tiles) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 4, 4, true>), rg, dim3(256), 0, cx.stream, B, it));
             else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
         } else {
             const dim3 rg((div_up(d.ext_cap, 256) + 7) & ~7, 1, S);
             if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 8, 4>), rg, dim3(256), 0, cx.stream, B, it));
             else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 2, 4>), rg, dim3(256), 0, cx.stream, B, it));
+            else if (a.lds_tiles) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 4, 4, true>), rg, dim3(256), 0, cx.stream, B, it));
             else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
         }
     }

@@ -113,6 +113,8 @@ struct LidarDev {
     unsigned char* fitOk = nullptr;                        // [ext_cap]
     int icp_g0 = 4;                                        // lanes per feature in GN iteration 0 (whole unit ball; LVI_ICP_G0; measured with 16 scans in flight: 8 lanes 5 030, 4 lanes 5 245 scans/s)
     int icp_g1 = 4;                                        // lanes per feature in GN iterations >= 1 (LVI_ICP_G1 = 8 | 4 | 2 | 84 (8 lanes, batches of 4))
+    bool knn_tiles = false;                                // LVI_KNN_TILES=1 at create: a wavefront's searches read an LDS tile of the index when its features' reach fits one (tests: same bits)
+    int icp_stamp_iter = -1;                               // LVI_ICP_STAMP_ITER: the GN iteration whose phase stamps LVI_DBG_ICP_CYCLES shows (-1: the last launched)
     int icp_wide_from = 3;                                 // first GN iteration that runs 256 features per workgroup (LVI_ICP_WIDE_FROM)
     float4* nnRef = nullptr;                               // [ext_cap] position at the feature's last search + squared lower bound on the distance to the map points outside its five
     bool knn_skip = true;                                  // LVI_KNN_NO_SKIP=1 at create: every iteration >= 1 runs its (bounded) search (tests: same bits)

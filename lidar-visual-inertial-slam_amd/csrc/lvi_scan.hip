@@ -976,6 +976,8 @@ void lidar_allocate(LidarDev& d)
     if (d.P.batch_scans > 1) { d.icp_g1 = 2; d.icp_wide_from = 1; }      // (256 features per workgroup from iteration 1 on: 8 040 vs 7 930 scans/s; a single scan: 640 vs 612 us)
     // (2 lanes per feature in throughput mode: 16 scans in flight 5 315 scans/s with 2 lanes, 5 140 with 4; one scan alone: 25 vs 20 us per iteration)
     { const char* e = getenv("LVI_ICP_G0"); if (e) d.icp_g0 = atoi(e); }
+    { const char* e = getenv("LVI_KNN_TILES"); d.knn_tiles = e && e[0] == '1'; }
+    { const char* e = getenv("LVI_ICP_STAMP_ITER"); if (e) d.icp_stamp_iter = atoi(e); }
     { const char* e = getenv("LVI_ICP_WIDE_FROM"); if (e) d.icp_wide_from = std::max(1, atoi(e)); }
     { const char* e = getenv("LVI_ICP_G1"); if (e) d.icp_g1 = atoi(e); if (!d.knn_bound) d.icp_g1 = 8; }
     d.feat_handover_ticks = d.P.sector_handover_wait_us < 0 ? 0 : 100ll * (d.P.sector_handover_wait_us > 0 ? d.P.sector_handover_wait_us : 2000);

@@ -874,9 +874,14 @@ def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
     A = pkg._abi
     S = pkg.synth
     out = []
-    modes = (dict(LVI_KNN_NO_BOUND="1"), dict(LVI_KNN_NO_SKIP="1"), dict(), dict(LVI_KNN_SLACK="0"), dict(LVI_KNN_SLACK="0.2"), dict(LVI_ICP_G1="2"))
+    # … and the same whether a wavefront searches its LDS tile of the index or global memory (LVI_KNN_TILES=1), with 64 or 256
+    # features per workgroup (LVI_ICP_WIDE_FROM), with 2, 4 or 8 lanes per feature
+    modes = (dict(LVI_KNN_NO_BOUND="1"), dict(LVI_KNN_NO_SKIP="1"), dict(), dict(LVI_KNN_SLACK="0"), dict(LVI_KNN_SLACK="0.2"), dict(LVI_ICP_G1="2"),
+             dict(LVI_KNN_TILES="1"), dict(LVI_KNN_TILES="1", LVI_KNN_NO_BOUND="1"), dict(LVI_ICP_WIDE_FROM="1"), dict(LVI_ICP_WIDE_FROM="99", LVI_ICP_G0="8"),
+             dict(LVI_ICP_G0="2", LVI_ICP_G1="8"))
+    ALL = ("LVI_KNN_NO_BOUND", "LVI_KNN_NO_SKIP", "LVI_KNN_SLACK", "LVI_ICP_G1", "LVI_ICP_G0", "LVI_KNN_TILES", "LVI_ICP_WIDE_FROM")
     for env in modes:
-        for k in ("LVI_KNN_NO_BOUND", "LVI_KNN_NO_SKIP", "LVI_KNN_SLACK", "LVI_ICP_G1"):
+        for k in ALL:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -894,7 +899,7 @@ def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
                 searches.append((int(cyc[15]), (c["corner_ds"] + c["surf_ds"]) * r["iters"]))
             g.close()
         out.append((rows, searches))
-    for k in ("LVI_KNN_NO_BOUND", "LVI_KNN_NO_SKIP", "LVI_KNN_SLACK", "LVI_ICP_G1"):
+    for k in ALL:
         monkeypatch.delenv(k, raising=False)
     for rows, _ in out[1:]:
         for ra, rb in zip(out[0][0], rows):

@@ -18,8 +18,10 @@ g0.close()
 pose = S.loop_pose(0.37, 0.0, -0.02)
 scan = S.make_scan(100001, pose, 12345)
 guess = S.perturbed_guess(pose, 0)
-names = ["phase0", "knn_total", "merge", "fit_rows", "reduce_ticket", "total", "row_setup", "first_batch", "s_take", "s_solve", "", "", "s_total", "T", "bounded", "searches"]
+names = ["phase0", "knn_total", "merge", "fit_rows", "reduce_ticket", "total", "row_setup", "first_batch", "s_take", "s_solve", "rounds_direct", "rounds_tiled", "s_total", "T", "bounded", "searches"]
 for nb, g1 in (("0", os.environ.get("LVI_ICP_G1", "4")),):
+  for sit in os.environ.get("STAMP_ITERS", "-1").split(","):
+    os.environ["LVI_ICP_STAMP_ITER"] = sit
     os.environ["LVI_ICP_G1"] = g1
     os.environ["LVI_KNN_NO_BOUND"] = nb
     g = pkg.LidarHotpath(hip, **P)
@@ -28,7 +30,7 @@ for nb, g1 in (("0", os.environ.get("LVI_ICP_G1", "4")),):
         g.scan_upload(scan); g.scan_organize(); g.scan_extract(); g.scan_downsample()
         r = g.scan_match(guess)
     c = g.debug_get(A.DBG_ICP_CYCLES, np.int64)
-    print("no_bound" if nb == "1" else "bounded G1=" + g1, r["n_sel"][-1], r["pose"])
+    print("stamp iter", sit, "no_bound" if nb == "1" else "bounded G1=" + g1, r["n_sel"][-1])
     print("   ", {n: int(v) for n, v in zip(names, c) if n}, 'of', (g.counts()['corner_ds'] + g.counts()['surf_ds']) * r['iters'])
     g.prof_enable(True)
     g.scan_upload(scan); g.scan_organize(); g.scan_extract(); g.scan_downsample(); g.scan_match(guess)
