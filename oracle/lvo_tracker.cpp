@@ -10,10 +10,17 @@
 //   feature_tracker/src/feature_tracker.cpp:113   calcOpticalFlowPyrLK(cur,forw,pts,…,Size(21,21),3)
 //   feature_tracker/src/feature_tracker.cpp:166   goodFeaturesToTrack(forw,n_pts,N,0.01,MIN_DIST,mask)
 // Choices where OpenCV's result depends on the build:
-//   * LK accumulators (A11,A12,A22,b1,b2): OpenCV uses int64 on ARM NEON builds and float on
-//     x86.  The reference targets a Jetson Orin NX (aarch64, readme.md:4), so the exact int64
-//     form is restated; it is order-independent, which is also what makes a bit-exact GPU
-//     implementation possible.
+//   * LK accumulators (A11,A12,A22,b1,b2): OpenCV's scalar code sums them in its `acctype` — float in
+//     the build SURVEY App. A.6 describes — and its SIMD paths sum the same products in four lanes:
+//     the float result depends on the build's summation order.  Two forms are restated:
+//       mode 0 (default)  exact integer sums (int64), converted to float once: the value every float
+//                         order approximates, order-independent, and therefore what a parallel
+//                         implementation can reproduce bit for bit;
+//       mode 1            SURVEY App. A.6 literally: float accumulators, one scalar addition per
+//                         pixel in row-major order, then x 2^-20.
+//     lvo_set_lk_accumulators(mode) switches (process-wide, test infrastructure only).  The measured
+//     difference between the two (status flips at the minEig test, positions) is reported by
+//     tests/test_gpu_tracker.py::test_lk_float_accumulator_variant_report and DESIGN.md 2.
 //   * Sobel / min-eigenvalue arithmetic: scalar (non-SIMD, non-fused) operation order.
 //   * single-threaded scalar code (real OpenCV uses SIMD and a thread pool — say so next to
 //     any speed-up quoted against this baseline).
@@ -28,6 +35,10 @@
 #include "../include/lvi_hotpath.h"
 
 void lvo_set_error(const char* msg);   // lvo_lidar.cpp
+
+static int g_lk_acc_mode = 0;                   // 0: exact integer sums; 1: float sums, scalar row-major order
+extern "C" void lvo_set_lk_accumulators(int mode) { g_lk_acc_mode = mode ? 1 : 0; }
+extern "C" int lvo_get_lk_accumulators(void) { return g_lk_acc_mode; }
 
 namespace {
 
@@ -144,6 +155,7 @@ void lkLevel(const Image8& I, const Deriv16& dI, const Image8& J, const float* p
         int iw10 = cvRound((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+        float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f;
         for (int y = 0; y < win; y++)
             for (int x = 0; x < win; x++) {
                 int X = ipx + x, Y = ipy + y;
@@ -156,8 +168,12 @@ void lkLevel(const Image8& I, const Deriv16& dI, const Image8& J, const float* p
                 iA11 += (int)(ixval * ixval);
                 iA12 += (int)(ixval * iyval);
                 iA22 += (int)(iyval * iyval);
+                fA11 += (float)(ixval * ixval);
+                fA12 += (float)(ixval * iyval);
+                fA22 += (float)(iyval * iyval);
             }
         float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
+        if (g_lk_acc_mode == 1) { A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE; }
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
         if (minEig < minEigThreshold || D < FLT_EPSILON) {
@@ -179,6 +195,7 @@ void lkLevel(const Image8& I, const Deriv16& dI, const Image8& J, const float* p
             iw10 = cvRound((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int64_t ib1 = 0, ib2 = 0;
+            float fb1 = 0.f, fb2 = 0.f;
             for (int y = 0; y < win; y++)
                 for (int x = 0; x < win; x++) {
                     int X = inx + x, Y = iny + y;
@@ -186,8 +203,11 @@ void lkLevel(const Image8& I, const Deriv16& dI, const Image8& J, const float* p
                              - IWin[(size_t)y * win + x];
                     ib1 += (int)(diff * dIWin[((size_t)y * win + x) * 2]);
                     ib2 += (int)(diff * dIWin[((size_t)y * win + x) * 2 + 1]);
+                    fb1 += (float)(diff * dIWin[((size_t)y * win + x) * 2]);
+                    fb2 += (float)(diff * dIWin[((size_t)y * win + x) * 2 + 1]);
                 }
             float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+            if (g_lk_acc_mode == 1) { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
             float dx = (float)((A12 * b2 - A22 * b1) * D);
             float dy = (float)((A12 * b1 - A11 * b2) * D);
             nextx += dx; nexty += dy;

@@ -112,6 +112,7 @@ def run(n_cases, seed, only=None, verbose=False):
         scene = scenes[mseed]
         o = pkg.LidarHotpath(oracle, **kw); g = pkg.LidarHotpath(hip, voxel_mode=voxel_mode, **kw)
         diffs, kinds = [], set()
+        cascade_seen = False
         for r in reps:
             pose = S.loop_pose(*r["pose_args"])
             scan = S.make_scan(r["n_raw"], pose, r["scan_seed"], noise=r["noise"])
@@ -190,7 +191,9 @@ def run(n_cases, seed, only=None, verbose=False):
             # allowed up to 6 of thousands as long as the first difference is 1 - 2 features and the final poses agree to 1e-5
             cascade_bad = bool(gaps) and (first_gap > 2 or max(gaps) > 6 or (max(gaps) > 2 and seam_diff >= 1e-5))
             nsel_gap = 0 if not gaps else (3 if cascade_bad else min(max(gaps), 2))
-            if gaps and max(gaps) > 2 and nsel_gap <= 2:
+            cascade = bool(gaps) and max(gaps) > 2 and nsel_gap <= 2
+            cascade_seen = cascade_seen or cascade
+            if cascade:
                 print("NOTE", case, f"knife edge with a cascade: selected counts differ by {gaps} (first {first_gap}), pose diff {seam_diff:.3e}", flush=True)
             if so["status"] == 0 and so["iters"] == sg["iters"]:
                 seam_worst = max(seam_worst, seam_diff)
@@ -217,7 +220,7 @@ def run(n_cases, seed, only=None, verbose=False):
             bad += 1
             kind = next(k for k in ("unexplained", "ties", "second_ds", "gn", "knife") if k in kinds)
             classes[kind] += 1
-            report.append(dict(case=case, kind=kind, params=kw, diffs=diffs))
+            report.append(dict(case=case, kind=kind, params=kw, diffs=diffs, cascade=bool(cascade_seen)))
             print("DIFF", case, kind, kw, diffs, flush=True)
         if case % 10 == 9:
             print(f"[{case + 1}/{n_cases}] differing={bad} {classes} worst_pose_diff={worst:.3e} seam_worst={seam_worst:.3e} {time.time() - t0:.0f}s", flush=True)

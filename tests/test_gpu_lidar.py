@@ -322,6 +322,26 @@ def test_map_build_and_knn_exact(pkg, pair, scene):
         mism = (io != ig).any(axis=1)
         assert mism.mean() < 2e-3, f"{mism.sum()} of {len(q)} queries differ"
         np.testing.assert_allclose(do[~mism], dg[~mism], rtol=1e-4, atol=1e-6)
+    # ---- the identical-input leg: both libraries index the SAME DS map — the HIP path's, handed over as a raw
+    # map (one point per voxel: its centroid is the point itself on both sides) — and then nothing is tolerated: indices and
+    # squared distances bit for bit
+    for h in (o, g):
+        h.map_set(mcg, msg)
+    (aco, aso), (acg, asg) = o.get_map_ds(), g.get_map_ds()
+    np.testing.assert_array_equal(xyzi(aco).view(np.uint32), xyzi(acg).view(np.uint32))
+    np.testing.assert_array_equal(xyzi(aso).view(np.uint32), xyzi(asg).view(np.uint32))
+    for which, m in ((0, acg), (1, asg)):
+        q = xyzi(m)[rng.integers(0, len(m), 4000)].copy()
+        q[:, :3] += rng.normal(0, 0.15, (4000, 3)).astype(np.float32)
+        q[-200:, :3] += 50.0
+        io, do = o.debug_knn(which, q)
+        ig, dg = g.debug_knn(which, q)
+        assert (io[:, 4] >= 0).sum() > 500
+        # a genuine distance tie between two map points may be listed in either order by the kd-tree: compare as (distance, index) sets
+        tie = (do[:, 1:] == do[:, :-1]).any(axis=1) & (io[:, 4] >= 0)
+        np.testing.assert_array_equal(io[~tie], ig[~tie])
+        np.testing.assert_array_equal(bits(do), bits(dg))
+        np.testing.assert_array_equal(np.sort(io[tie], axis=1), np.sort(ig[tie], axis=1))
 
 
 def test_knn_index_bit_exact_on_identical_map(pkg, oracle, hip):
@@ -410,6 +430,23 @@ def test_residuals_at_fixed_pose(pkg, pair, scene):
         assert (fo != fg).mean() < 5e-3, f"flag mismatch {(fo != fg).sum()} / {len(fo)}"
         d = np.abs(xyzi(co)[both] - xyzi(cg)[both])
         assert np.quantile(d, 0.999) < 2e-3 and np.median(d) < 1e-5, (np.quantile(d, 0.999), np.median(d))
+    # ---- the identical-input leg: the same DS map and the same DS scan on both sides (the HIP path's, handed
+    # over as raw clouds with one point per voxel).  Then the neighbours are the same and the selection flags must be EQUAL; the
+    # coefficients differ only by the rounding of the two eigen / QR restatements
+    (mcg, msg), (scg, ssg) = g.get_map_ds(), g.get_scan_ds()
+    for h in (o, g):
+        h.map_set(mcg, msg)
+        h.scan_to_map(scg, ssg, scene["guess"])                   # uploads the clouds as features, second-stage DS, match
+    assert o.counts()["corner_ds"] == g.counts()["corner_ds"] == len(scg) and o.counts()["surf_ds"] == g.counts()["surf_ds"] == len(ssg)
+    for a, b in zip(o.get_scan_ds(), g.get_scan_ds()):
+        np.testing.assert_array_equal(xyzi(a).view(np.uint32), xyzi(b).view(np.uint32))
+    for which in (0, 1):
+        co, fo = o.debug_residuals(which, scene["guess"])
+        cg, fg = g.debug_residuals(which, scene["guess"])
+        np.testing.assert_array_equal(fo, fg)
+        both = fo == 1
+        d = np.abs(xyzi(co)[both] - xyzi(cg)[both])
+        assert d.max() < 2e-4 and np.median(d) < 1e-6, (d.max(), np.median(d))
 
 
 # ----------------------------------------------------------------------------- a-9, a-10
@@ -432,6 +469,17 @@ def test_scan_to_map_pose_parity(pkg, pair, scene):
     assert np.abs(rg["pose"][:3] - scene["pose"][:3]).max() < 0.003
     jo, jg = o.debug_get(A.DBG_ICP_JTJ, np.float32), g.debug_get(A.DBG_ICP_JTJ, np.float32)
     np.testing.assert_allclose(jo[:27], jg[:27], rtol=2e-3, atol=1e-2)
+    # ---- the identical-input leg: the HIP path's DS map and DS scan on both sides: selected counts equal in
+    # every iteration, the same number of iterations, poses far inside the bar
+    (mcg, msg), (scg, ssg) = g.get_map_ds(), g.get_scan_ds()
+    for h in (o, g):
+        h.map_set(mcg, msg)
+    xo, xg = o.scan_to_map(scg, ssg, scene["guess"]), g.scan_to_map(scg, ssg, scene["guess"])
+    assert xo["status"] == xg["status"] == 0 and xo["iters"] == xg["iters"] and xo["degenerate"] == xg["degenerate"]
+    np.testing.assert_array_equal(np.array(xo["n_sel"]), np.array(xg["n_sel"]))
+    assert np.abs(xo["pose"] - xg["pose"]).max() < 2e-5, np.abs(xo["pose"] - xg["pose"])
+    for h in (o, g):
+        h.map_set(scene["map_corner"], scene["map_surf"])
     # IMU hint path (transformUpdate slerp) and the one-call seam
     imu = dict(imu_available=1, roll=0.012, pitch=-0.018, yaw=0.0)
     c, s = o.get_features()

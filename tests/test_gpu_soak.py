@@ -33,6 +33,18 @@ def test_lidar_soak_classified():
     assert s["classes"]["unexplained"] == 0, s["report"]
     for r in s["report"]:
         assert r["kind"] in ("ties", "second_ds", "gn", "knife"), r
+    # the class of a known case must not drift (advisor, round 2): a tie stays a tie, a second-stage count a second-stage count; a
+    # Gauss-Newton knife edge may show as "gn" or "knife" (which iteration the one feature flips in follows the last bit of a pose);
+    # a known case that no longer differs at all is fine too
+    got = {r["case"]: r["kind"] for r in s["report"]}
+    allowed = dict(ties=("ties",), second_ds=("second_ds",), gn=("gn", "knife"), knife=("gn", "knife"))
+    for case, kind in KNOWN.items():
+        if case in got:
+            assert got[case] in allowed[kind], (case, kind, got[case])
+    # the cascade allowance of the classifier (first difference <= 2 features, later iterations <= 6, final poses within 1e-5) was
+    # measured on case 611 of the seed-31337 stream only; no case of THIS list may need it
+    for r in s["report"]:
+        assert not r.get("cascade", False), r
     # with identical inputs the GN path agrees to far better than the bar in every executed case
     assert s["worst_pose_diff_seam"] < 1e-4
     print("lidar soak:", s["executed"], "cases,", s["differing"], "differing:", s["classes"], "worst staged pose diff %.2e" % s["worst_pose_diff_staged"])

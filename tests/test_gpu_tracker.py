@@ -199,7 +199,17 @@ def test_mei_undistort_bit_exact(pkg, pair):
     o, g = pair
     cam = dict(xi=1.9926618269451453, k1=-0.0399258932468764, k2=0.15160828121223818, p1=0.00017756967825777937, p2=-0.0011531239076798612,
                gamma1=669.8940458885896, gamma2=669.1450614220616, u0=377.9459252967363, v0=279.63655686698144)
+    # the reference's own intrinsics (config_pkg/config/params_camera.yaml:35-45 through tests/golden/reference_params.json), 1024 x 576
+    import json, os
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_params.json")))["camera"]
+    yaml_cam = {k: float(ref[k]) for k in ("xi", "k1", "k2", "p1", "p2", "gamma1", "gamma2", "u0", "v0")}
     rng = np.random.default_rng(6)
+    xy_ref = np.stack([rng.uniform(0, 1024, 1000), rng.uniform(0, 576, 1000)], axis=1).astype(np.float32)
+    a, b = o.undistort_points(yaml_cam, xy_ref), g.undistort_points(yaml_cam, xy_ref)
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+    ok = ~np.isnan(a)
+    assert ok.mean() > 0.9
+    np.testing.assert_array_equal(bits(a)[ok], bits(b)[ok])
     xy = np.stack([rng.uniform(0, 752, 1000), rng.uniform(0, 480, 1000)], axis=1).astype(np.float32)
     for c in (cam, dict(cam, xi=1.0), dict(cam, k1=0.0, k2=0.0, p1=0.0, p2=0.0), dict(cam, xi=0.0)):
         a, b = o.undistort_points(c, xy), g.undistort_points(c, xy)
@@ -209,3 +219,50 @@ def test_mei_undistort_bit_exact(pkg, pair):
         ok = ~np.isnan(a)
         assert ok.mean() > 0.5
         np.testing.assert_array_equal(bits(a)[ok], bits(b)[ok])
+
+
+def test_lk_float_accumulator_variant_report(pkg, oracle, hip):
+    """VERDICT r2 item 2.  OpenCV's LK sums A11 / A12 / A22 / b1 / b2 in float, in an order that depends on the
+    build (scalar or four SIMD lanes); the oracle's default form and the HIP kernel hold the exact integer sums those floats
+    approximate.  This test measures, over >= 400 random cases (sizes 64x48 ... 1280x720, motions 0.3 ... 25 px), what the choice
+    changes: status flips (the minEig < 1e-4 test, the border exit) and the position difference of the points both forms track —
+    HIP against the oracle's LITERAL App. A.6 form (float accumulators, scalar row-major order).  The HIP path stays bit-exact
+    against the integer form (test_lk_bit_exact_and_tracks_the_motion, the tracker soak)."""
+    import ctypes
+    S = pkg.synth
+    oracle.dll.lvo_set_lk_accumulators.argtypes = [ctypes.c_int]
+    rng = np.random.default_rng(2026)
+    kw = dict(max_width=1280, max_height=720, max_features=1024)
+    o = pkg.TrackerHotpath(oracle, **kw); g = pkg.TrackerHotpath(hip, **kw)
+    sizes = [(64, 48), (97, 61), (320, 240), (333, 251), (640, 480), (752, 480), (1024, 576), (1280, 720)]
+    n_cases, n_pts, flips, both, dmax, d_all = 0, 0, 0, 0, 0.0, []
+    try:
+        oracle.dll.lvo_set_lk_accumulators(1)
+        while n_cases < 400:
+            w, h = sizes[int(rng.integers(0, len(sizes)))]
+            img0 = S.make_texture(w, h, int(rng.integers(1 << 30)))
+            if rng.random() < 0.2:
+                img0 = np.clip(img0.astype(np.int32) * int(rng.integers(1, 4)) - int(rng.integers(0, 200)), 0, 255).astype(np.uint8)
+            img1 = S.warp_homography(img0, S.small_motion_homography(w, h, int(rng.integers(1 << 20)), max_px=float(rng.choice([0.3, 2.0, 5.0, 12.0, 25.0]))))
+            k = 150 if w * h < 400000 else 60
+            pts = np.stack([rng.uniform(-5, w + 5, k), rng.uniform(-5, h + 5, k)], axis=1).astype(np.float32)
+            xo, so, _ = o.lk_track(img0, img1, pts)
+            xg, sg, _ = g.lk_track(img0, img1, pts)
+            n_cases += 1; n_pts += k
+            flips += int((so != sg).sum())
+            kk = (so == 1) & (sg == 1)
+            both += int(kk.sum())
+            if kk.any():
+                d = np.abs(xo[kk] - xg[kk]).max(axis=1)
+                d_all.append(d); dmax = max(dmax, float(d.max()))
+    finally:
+        oracle.dll.lvo_set_lk_accumulators(0)
+    d_all = np.concatenate(d_all)
+    rep = dict(cases=n_cases, points=n_pts, status_flips=flips, flip_rate=flips / n_pts, tracked_by_both=both, max_dpos_px=dmax,
+               p99_dpos_px=float(np.quantile(d_all, 0.99)), median_dpos_px=float(np.median(d_all)), frac_identical=float((d_all == 0).mean()))
+    print("LK float-accumulator variant vs exact integer sums (HIP):", rep)
+    # what the measurement must keep showing: the choice is a rounding-level matter — flips are rare (points sitting on the minEig
+    # threshold or the border) and common points agree far below a hundredth of a pixel
+    assert rep["flip_rate"] < 5e-3, rep
+    assert rep["p99_dpos_px"] < 1e-2, rep
+    o.close(); g.close()

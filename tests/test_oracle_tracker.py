@@ -238,3 +238,30 @@ def test_mei_undistortion_round_trip(pkg, T):
     back = _mei_project(dict(pin, xi=1.0), np.concatenate([un1, np.ones((len(un1), 1))], axis=1))
     assert np.abs(back - xy).max() < 2e-3
     assert len(T.undistort_points(MEI, np.zeros((0, 2), np.float32))) == 0
+
+
+def test_lk_accumulator_switch(pkg, T):
+    """lvo_set_lk_accumulators: mode 1 = SURVEY App. A.6 literally (float sums, scalar row-major order), mode 0 = exact integer sums.
+    On a textured pair the two agree to rounding; the switch is process-wide and must be put back"""
+    import ctypes
+    S = pkg.synth
+    lib = T.lib
+    lib.dll.lvo_set_lk_accumulators.argtypes = [ctypes.c_int]
+    lib.dll.lvo_get_lk_accumulators.restype = ctypes.c_int
+    assert lib.dll.lvo_get_lk_accumulators() == 0
+    w, h = 320, 240
+    img0 = S.make_texture(w, h, 11)
+    img1 = S.warp_homography(img0, S.small_motion_homography(w, h, 3, max_px=3.0))
+    pts = T.good_features(img0, 80, 0.01, 10.0)
+    x0, s0, _ = T.lk_track(img0, img1, pts)
+    try:
+        lib.dll.lvo_set_lk_accumulators(1)
+        assert lib.dll.lvo_get_lk_accumulators() == 1
+        x1, s1, _ = T.lk_track(img0, img1, pts)
+    finally:
+        lib.dll.lvo_set_lk_accumulators(0)
+    k = (s0 == 1) & (s1 == 1)
+    assert k.sum() >= 0.9 * len(pts)
+    assert np.abs(x0[k] - x1[k]).max() < 1e-2
+    x2, s2, _ = T.lk_track(img0, img1, pts)
+    np.testing.assert_array_equal(x0, x2)
