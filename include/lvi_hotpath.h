@@ -416,13 +416,27 @@ int32_t lvi_tracker_get_lk(lvi_tracker *t, float *forw_xy, uint8_t *status, floa
 int32_t lvi_tracker_set_mask(lvi_tracker *t, const uint8_t *mask, int32_t w, int32_t h, int32_t stride); /* NULL → all 255 */
 int32_t lvi_tracker_run_gftt(lvi_tracker *t, int32_t max_corners);                                 /* on forw */
 int32_t lvi_tracker_get_gftt(lvi_tracker *t, float *xy, int32_t capacity, int32_t *n);
+/* a-13 setMask (feature_tracker.cpp:36-69), the raster half: mask = 255, then cv::circle(mask, pt, radius, 0, -1) around every listed
+ *      point (centres rounded as Mat::at(Point2f) / cv::circle round them).  The caller keeps the ordering by track_cnt and the
+ *      "is this point still free" walk (:50-67) — 150 points, host — and hands over the points it kept: 1.2 KB cross the bus instead
+ *      of the W x H mask.  Enqueued, not synchronised. */
+int32_t lvi_tracker_set_mask_circles(lvi_tracker *t, const float *centers_xy, int32_t n, int32_t radius);
+/* a-12 cv::goodFeaturesToTrack(forw_img, n_pts, MAX_CNT - forw_pts.size(), 0.01, MIN_DIST, mask) (feature_tracker.cpp:166), enqueued
+ *      only: lvi_tracker_finish_frame fetches the corners. */
+int32_t lvi_tracker_run_gftt_async(lvi_tracker *t, int32_t max_corners);
+/* The end of readImage (feature_tracker.cpp:166-205) in ONE read of the device: the corners of a pending lvi_tracker_run_gftt_async
+ * (n_new, new_xy; none pending: n_new = 0) and — cam != NULL — undistortedPoints() (f-3, :298-311) of cur_pts of the next frame
+ * = [kept_xy ; new corners] (addPoints :71-79 appends them in this order): un_xy receives n_kept + n_new (x, y) pairs. */
+int32_t lvi_tracker_finish_frame(lvi_tracker *t, const lvi_mei_params *cam, const float *kept_xy, int32_t n_kept,
+                                 float *new_xy, int32_t new_capacity, int32_t *n_new, float *un_xy);
 
 enum {
     LVI_TDBG_PYRAMID_L1 = 1,   /* u8 level-1 image of forw (pyrDown) */
     LVI_TDBG_PYRAMID_L2 = 2,
     LVI_TDBG_PYRAMID_L3 = 3,
     LVI_TDBG_MINEIG     = 4,   /* f32[h*w] cornerMinEigenVal map of forw */
-    LVI_TDBG_GFTT_NCAND = 5    /* i32[1]  number of local-maximum candidates before the distance filter */
+    LVI_TDBG_GFTT_NCAND = 5,   /* i32[1]  number of local-maximum candidates before the distance filter */
+    LVI_TDBG_MASK       = 6    /* u8[h*w] the mask goodFeaturesToTrack reads (lvi_tracker_set_mask / lvi_tracker_set_mask_circles) */
 };
 int32_t lvi_tracker_debug_get(lvi_tracker *t, int32_t what, void *dst, int64_t capacity_bytes, int64_t *n_bytes);
 

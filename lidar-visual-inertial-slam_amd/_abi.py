@@ -30,7 +30,7 @@ DBG_FEAT_CYCLES = 11
 DBG_MAP_CORNER_RAW = 13
 DBG_MAP_SURF_RAW = 14
 DBG_ICP_CYCLES = 12
-TDBG_PYRAMID_L1, TDBG_PYRAMID_L2, TDBG_PYRAMID_L3, TDBG_MINEIG, TDBG_GFTT_NCAND = 1, 2, 3, 4, 5
+TDBG_PYRAMID_L1, TDBG_PYRAMID_L2, TDBG_PYRAMID_L3, TDBG_MINEIG, TDBG_GFTT_NCAND, TDBG_MASK = 1, 2, 3, 4, 5, 6
 
 PT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4")])
 LIVOX_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("reflectivity", "u1"), ("tag", "u1"),
@@ -167,6 +167,9 @@ SIGNATURES = {
     "lvi_tracker_set_mask": (_i32, [_vp, _vp, _i32, _i32, _i32]),
     "lvi_tracker_run_gftt": (_i32, [_vp, _i32]),
     "lvi_tracker_get_gftt": (_i32, [_vp, _vp, _i32, _P(_i32)]),
+    "lvi_tracker_set_mask_circles": (_i32, [_vp, _vp, _i32, _i32]),
+    "lvi_tracker_run_gftt_async": (_i32, [_vp, _i32]),
+    "lvi_tracker_finish_frame": (_i32, [_vp, _P(MeiParams), _vp, _i32, _vp, _i32, _P(_i32), _vp]),
     "lvi_tracker_debug_get": (_i32, [_vp, _i32, _vp, _i64, _P(_i64)]),
     "lvi_tracker_prof_enable": (_i32, [_vp, _i32]),
     "lvi_tracker_prof_reset": (_i32, [_vp]),

@@ -146,9 +146,10 @@ __device__ __forceinline__ void mei_distortion(const lvi_mei_params& c, double p
     duy = puy * rad_dist_u + 2.0 * c.p2 * mxy_u + c.p1 * (rho2_u + 2.0 * my2_u);
 }
 
-__global__ __launch_bounds__(64) void mei_undistort_kernel(lvi_mei_params c, const float* __restrict__ xy, int n, float* __restrict__ out)
+__global__ __launch_bounds__(64) void mei_undistort_kernel(lvi_mei_params c, const float* __restrict__ xy, int n, float* __restrict__ out, const int* __restrict__ n_dev = nullptr)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
+    if (n_dev) n = min(n, *n_dev);                  // (the count of a device-side concatenation)
     if (i >= n) return;
     const double inv_K11 = 1.0 / c.gamma1, inv_K13 = -c.u0 / c.gamma1, inv_K22 = 1.0 / c.gamma2, inv_K23 = -c.v0 / c.gamma2;
     const bool noDistortion = c.k1 == 0.0 && c.k2 == 0.0 && c.p1 == 0.0 && c.p2 == 0.0;
@@ -166,6 +167,55 @@ __global__ __launch_bounds__(64) void mei_undistort_kernel(lvi_mei_params c, con
     out[2 * i] = (float)(mx_u / bz); out[2 * i + 1] = (float)(my_u / bz);
 }
 
+// setMask (feature_tracker.cpp:36-69): mask = 255, then cv::circle(mask, pt, MIN_DIST, 0, -1) around every kept point.  The
+// filled circle is OpenCV's midpoint raster (FillCircle): row cy +- dy spans cx +- dx and row cy +- dx spans cx +- dy for the
+// (dx, dy) the integer error recurrence visits; hw[j] = the widest of the spans of row offset j.  One thread per (circle, row).
+struct CircleArgs { uint8_t* mask; int w, h; const float* centers; int n; int radius; };
+__global__ __launch_bounds__(256) void mask_fill_kernel(CircleArgs a)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i + 16 <= (size_t)a.w * a.h) *reinterpret_cast<uint4*>(a.mask + i) = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    else for (size_t k = i; k < (size_t)a.w * a.h; k++) a.mask[k] = 255;
+}
+__global__ __launch_bounds__(64) void mask_circles_kernel(CircleArgs a)
+{
+    __shared__ int hw[128];
+    const int r = a.radius;
+    if (threadIdx.x == 0) {
+        for (int j = 0; j <= r; j++) hw[j] = -1;
+        int err = 0, dx = r, dy = 0, plus = 1, minus = (r << 1) - 1;
+        while (dx >= dy) {
+            hw[dy] = max(hw[dy], dx); hw[dx] = max(hw[dx], dy);
+            dy++;
+            err += plus; plus += 2;
+            const int m = (err <= 0) - 1;
+            err -= minus & m; dx += m; minus -= m & 2;
+        }
+    }
+    __syncthreads();
+    const int c = blockIdx.x;
+    if (c >= a.n) return;
+    const int cx = (int)rintf(a.centers[2 * c]), cy = (int)rintf(a.centers[2 * c + 1]);      // Mat::at(Point2f) / cv::circle round the centre (cvRound)
+    for (int j = threadIdx.x; j <= 2 * r; j += 64) {
+        const int off = j - r, y = cy + off, half = hw[off < 0 ? -off : off];
+        if (y < 0 || y >= a.h || half < 0) continue;
+        const int x0 = max(cx - half, 0), x1 = min(cx + half, a.w - 1);
+        for (int x = x0; x <= x1; x++) a.mask[(size_t)y * a.w + x] = 0;
+    }
+}
+
+// undistortedPoints over [the kept points (host) ; the corners goodFeaturesToTrack just found (device)]: cur_pts of the next frame
+__global__ __launch_bounds__(64) void frame_concat_kernel(const float* __restrict__ kept, int n_kept, const float* __restrict__ found, const int* __restrict__ n_found,
+                                                          int cap, float* __restrict__ all_xy, int* __restrict__ n_all)
+{
+    const int nf = min(max(*n_found, 0), cap);
+    const int n = min(n_kept + nf, cap);
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float* src = i < n_kept ? kept + 2 * i : found + 2 * (i - n_kept);
+        all_xy[2 * i] = src[0]; all_xy[2 * i + 1] = src[1];
+    }
+    if (threadIdx.x == 0) *n_all = n;
+}
 __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
 {
     constexpr int TW = LK_WIN_MAX + 3;             // 24: source tile (window + 1 for bilinear + 1 on each side for Scharr)
@@ -525,6 +575,7 @@ __global__ __launch_bounds__(256) void gftt_emit_kernel(GfttArgs a)
 }
 
 struct PickArgs {
+    const unsigned *keysA;
     const unsigned *valsA, *valsB; const int* d_nbits; const int* total;
     int w, h, max_corners, cap; double min_dist;
     float* out_xy; int* out_n; int* ncand;
@@ -534,14 +585,43 @@ struct PickArgs {
 // the accepted corners of the 3 x 3 grid cells around it (cell = min_dist, as OpenCV's own grid): the cells keep up to four
 // accepted indices each in LDS (corners at least min_dist apart: two fit a cell), so a candidate reads a handful of entries
 // instead of walking all accepted corners; a fifth corner in one cell, or a grid beyond the LDS budget, falls back to that walk.
-__global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
+// SORTLDS = false: the candidates arrive sorted (12-launch radix sort), one wavefront picks.
+// SORTLDS = true (at most GFTT_LDS_MAX candidates — a 1280 x 720 frame has a few thousand): ONE workgroup of 1024 threads sorts
+// the (value, address) keys in LDS (bitonic; the keys are unique: ~value bits, then ~address, i.e. descending value, higher
+// address first among equal values — cv::goodFeaturesToTrack's greaterThanPtr order) and its first wavefront picks from LDS:
+// one launch instead of thirteen.  The host chooses by the candidate count's bound; gftt_sortpick_kernel exits when the count
+// exceeds the LDS capacity and the radix path runs instead (a.use_lds tells the two apart on the device).
+constexpr int GFTT_LDS_MAX = 8192;
+template <bool SORTLDS>
+__global__ __launch_bounds__(SORTLDS ? 1024 : 64) void gftt_pick_kernel(PickArgs a)
 {
-    constexpr int ACC_MAX = 4096, GRID_MAX = 8192, CELL_CAP = 4;
+    constexpr int ACC_MAX = SORTLDS ? 2048 : 4096, GRID_MAX = SORTLDS ? 4096 : 8192, CELL_CAP = 4;
     __shared__ short ax[ACC_MAX], ay[ACC_MAX], acx[ACC_MAX], acy[ACC_MAX];      // accepted corners and their grid cells (no division in the inner loop)
     __shared__ unsigned char gcnt[GRID_MAX];
     __shared__ unsigned short gent[GRID_MAX * CELL_CAP];
-    const unsigned* vals = rs_result_in_B(a.d_nbits[0]) ? a.valsB : a.valsA;
+    __shared__ unsigned long long skey[SORTLDS ? GFTT_LDS_MAX : 1];
     const int total = *a.total;
+    if (SORTLDS) {
+        if (total > GFTT_LDS_MAX) { if (threadIdx.x == 0) { *a.out_n = -2; *a.ncand = total; } return; }      // the host runs the radix form for this frame
+        int N = 64;
+        while (N < total) N <<= 1;
+        for (int i = threadIdx.x; i < N; i += 1024)
+            skey[i] = i < total ? (((unsigned long long)a.keysA[i] << 32) | (unsigned long long)(0xFFFFFFFFu - a.valsA[i])) : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = threadIdx.x; p < (N >> 1); p += 1024) {
+                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = i | j;
+                    const unsigned long long x = skey[i], y = skey[q];
+                    if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[q] = x; }
+                }
+                __syncthreads();
+            }
+        if (threadIdx.x >= 64) return;
+    } else {
+    }
+    const unsigned* vals = rs_result_in_B(a.d_nbits[0]) ? a.valsB : a.valsA;
+    auto cand = [&](int i) -> unsigned { return SORTLDS ? 0xFFFFFFFFu - (unsigned)skey[i] : vals[i]; };
     const int l = threadIdx.x;
     if (l == 0) *a.ncand = total;
     const bool filter = a.min_dist >= 1.0;
@@ -550,18 +630,18 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
     const int gw = (a.w + cell - 1) / cell, gh = (a.h + cell - 1) / cell;
     bool grid = filter && gw * gh <= GRID_MAX;
     if (grid) for (int c = l; c < gw * gh; c += 64) gcnt[c] = 0;
-    __syncthreads();
+    if (SORTLDS) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
     int nacc = 0;
     // one corner past the capacity is enough to know the result does not fit (it is counted, not stored)
     const int limit = (a.max_corners > 0) ? min(a.max_corners, a.cap + 1) : a.cap + 1;
     bool overflow = false;
-    unsigned pnext = l < total ? vals[l] : 0u;             // the next batch's candidates are in flight while this one is resolved
+    unsigned pnext = l < total ? cand(l) : 0u;             // the next batch's candidates are in flight while this one is resolved
     for (int base = 0; base < total && nacc < limit; base += 64) {
         const int i = base + l;
         bool alive = i < total;
         int x = 0, y = 0;
         const int p = (int)pnext;
-        pnext = i + 64 < total ? vals[i + 64] : 0u;
+        pnext = i + 64 < total ? cand(i + 64) : 0u;
         if (alive) { y = p / a.w; x = p - y * a.w; }
         const int xc = x / cell, yc = y / cell;
         if (alive && filter) {
@@ -616,9 +696,9 @@ __global__ __launch_bounds__(64) void gftt_pick_kernel(PickArgs a)
             if (nacc >= ACC_MAX && filter) { overflow = true; break; }
         }
         if (overflow) break;
-        __syncthreads();
+        if (SORTLDS) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
     }
-    if (l == 0) *a.out_n = overflow ? -1 : nacc;
+    if (l == 0) *a.out_n = overflow ? (SORTLDS ? -2 : -1) : nacc;      // (the LDS form's accepted list is half the radix form's: -2 = redo there)
 }
 
 int32_t tfail(int32_t code, const std::string& msg) { set_error(msg); return code; }
@@ -646,6 +726,12 @@ struct lvi_tracker {
     float* d_gftt_xy = nullptr;
     SortPlan sort;
     int gftt_n = 0, gftt_ncand = 0;
+    bool gftt_force_radix = false;     // LVI_GFTT_RADIX=1 at create: always the 12-launch radix sort + one-wavefront pick (tests: same corners)
+    bool gftt_pending = false; int gftt_pending_max = 0;       // lvi_tracker_run_gftt_async enqueued, result not fetched yet
+    float* d_centers = nullptr; float* h_centers[2] = {nullptr, nullptr}; hipEvent_t ev_centers[2] = {nullptr, nullptr}; int centers_slot = 0;
+    float* d_frame_out = nullptr;      // [4 + 2 F + 2 F] one block: {n_new, n_cand, n_all, 0}, the new corners, the undistorted points of [kept ; new]
+    float* h_frame_out = nullptr;      // pinned mirror
+    float* d_all_xy = nullptr;         // [2 F] kept ++ new
     // f-2 / f-3
     uint8_t *d_eq = nullptr, *d_lut = nullptr; float *d_un_in = nullptr, *d_un_out = nullptr;
     bool equalize = false; double clahe_clip = 3.0; int clahe_tx = 8, clahe_ty = 8;
@@ -696,6 +782,8 @@ void tracker_layout(AR& ar, lvi_tracker& t)
     t.d_stage = ar.template alloc<uint8_t>((size_t)W * H); t.d_eq = ar.template alloc<uint8_t>((size_t)W * H);
     t.d_lut = ar.template alloc<uint8_t>((size_t)CLAHE_MAX_TILES * CLAHE_MAX_TILES * 256);
     t.d_un_in = ar.template alloc<float>(2 * (size_t)F); t.d_un_out = ar.template alloc<float>(2 * (size_t)F);
+    t.d_centers = ar.template alloc<float>(2 * (size_t)F); t.d_all_xy = ar.template alloc<float>(2 * (size_t)F);
+    t.d_frame_out = ar.template alloc<float>(4 + 4 * (size_t)F);
 }
 
 // src (w x h, dense) → dst equalised; both device buffers of the handle
@@ -756,6 +844,7 @@ int32_t lvi_tracker_create(const lvi_tracker_params* p, int32_t device, lvi_trac
     if (device < 0 || device >= ndev) return tfail(LVI_ERR_NO_DEVICE, "device index out of range");
     lvi_tracker* t = new lvi_tracker();
     t->P = *p; t->device = device;
+    { const char* e = getenv("LVI_GFTT_RADIX"); t->gftt_force_radix = e && e[0] == '1'; }
     int32_t st = tguard(t, [&]() -> int32_t {
         LVI_HIP(hipStreamCreateWithFlags(&t->ctx.stream, hipStreamNonBlocking));
         t->ctx.prof = &t->prof;
@@ -767,10 +856,14 @@ int32_t lvi_tracker_create(const lvi_tracker_params* p, int32_t device, lvi_trac
             LVI_HIP(hipHostMalloc((void**)&t->h_frame[s], (size_t)t->P.max_width * t->P.max_height, hipHostMallocDefault));
             LVI_HIP(hipEventCreateWithFlags(&t->ev_frame[s], hipEventDisableTiming));
             LVI_HIP(hipEventRecord(t->ev_frame[s], t->ctx.stream));
+            LVI_HIP(hipHostMalloc((void**)&t->h_centers[s], sizeof(float) * 2 * (size_t)std::max(t->P.max_features, 64), hipHostMallocDefault));
+            LVI_HIP(hipEventCreateWithFlags(&t->ev_centers[s], hipEventDisableTiming));
+            LVI_HIP(hipEventRecord(t->ev_centers[s], t->ctx.stream));
             LVI_HIP(hipHostMalloc((void**)&t->h_pts[s], sizeof(float) * 2 * (size_t)std::max(t->P.max_features, 64), hipHostMallocDefault));
             LVI_HIP(hipEventCreateWithFlags(&t->ev_pts[s], hipEventDisableTiming));
             LVI_HIP(hipEventRecord(t->ev_pts[s], t->ctx.stream));
         }
+        LVI_HIP(hipHostMalloc((void**)&t->h_frame_out, sizeof(float) * (4 + 4 * (size_t)std::max(t->P.max_features, 64)), hipHostMallocDefault));
         LVI_HIP(hipStreamSynchronize(t->ctx.stream));
         return LVI_OK;
     });
@@ -790,8 +883,11 @@ void lvi_tracker_destroy(lvi_tracker* t)
         if (t->h_frame[s]) (void)hipHostFree(t->h_frame[s]);
         if (t->ev_frame[s]) (void)hipEventDestroy(t->ev_frame[s]);
         if (t->h_pts[s]) (void)hipHostFree(t->h_pts[s]);
+        if (t->h_centers[s]) (void)hipHostFree(t->h_centers[s]);
+        if (t->ev_centers[s]) (void)hipEventDestroy(t->ev_centers[s]);
         if (t->ev_pts[s]) (void)hipEventDestroy(t->ev_pts[s]);
     }
+    if (t->h_frame_out) (void)hipHostFree(t->h_frame_out);
     if (t->ctx.stream) (void)hipStreamDestroy(t->ctx.stream);
     delete t;
 }
@@ -859,7 +955,7 @@ int32_t lvi_undistort_points(lvi_tracker* t, const lvi_mei_params* cam, const fl
     if (n == 0) return LVI_OK;
     return tguard(t, [&]() -> int32_t {
         LVI_HIP(hipMemcpyAsync(t->d_un_in, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
-        LVI_LAUNCH(t->ctx, "mei_undistort", 16.0 * n, hipLaunchKernelGGL(mei_undistort_kernel, dim3(div_up(n, 64)), dim3(64), 0, t->ctx.stream, *cam, t->d_un_in, n, t->d_un_out));
+        LVI_LAUNCH(t->ctx, "mei_undistort", 16.0 * n, hipLaunchKernelGGL(mei_undistort_kernel, dim3(div_up(n, 64)), dim3(64), 0, t->ctx.stream, *cam, t->d_un_in, n, t->d_un_out, (const int*)nullptr));
         LVI_HIP(hipMemcpyAsync(un_xy, t->d_un_out, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, t->ctx.stream));
         LVI_HIP(hipStreamSynchronize(t->ctx.stream));
         return LVI_OK;
@@ -932,35 +1028,126 @@ int32_t lvi_tracker_set_mask(lvi_tracker* t, const uint8_t* mask, int32_t w, int
     });
 }
 
+namespace {
+// goodFeaturesToTrack on forw, enqueued only.  lds_form: the candidates are sorted and picked by ONE workgroup in LDS (a frame with
+// more than GFTT_LDS_MAX candidates reports -2 in d_out_n and is redone in the radix form by whoever fetches the result).
+void enqueue_gftt(lvi_tracker* t, int32_t max_corners, bool lds_form)
+{
+    const int w = t->w, h = t->h, npx = w * h;
+    GfttArgs a{};
+    a.img = t->pyr[t->forw].lv[0].px; a.mask = t->have_mask ? t->d_mask : nullptr; a.w = w; a.h = h;
+    a.eig = t->d_eig; a.maxord = t->d_maxord; a.maxPartial = t->d_maxPartial; a.thr = t->d_thr; a.blockCnt = t->d_blockCnt; a.total = t->d_total;
+    a.keysA = t->sort.keysA; a.valsA = t->sort.valsA; a.d_n = t->d_n; a.d_nbits = t->d_nbits; a.quality = t->P.gftt_quality;
+    const int nblk = div_up(npx, CAND_TILE);
+    LVI_LAUNCH(t->ctx, "gftt_mineig", 2.0 * npx + 4.0 * npx, hipLaunchKernelGGL(mineig_kernel, dim3(div_up(w, 32), div_up(h, 8)), dim3(256), 0, t->ctx.stream, a));
+    LVI_LAUNCH(t->ctx, "gftt_thr", 0, hipLaunchKernelGGL(gftt_thr_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, div_up(w, 32) * div_up(h, 8)));
+    LVI_LAUNCH(t->ctx, "gftt_count", 5.0 * npx, hipLaunchKernelGGL(gftt_count_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
+    LVI_LAUNCH(t->ctx, "gftt_scan", 0, hipLaunchKernelGGL(gftt_scan_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, nblk));
+    LVI_LAUNCH(t->ctx, "gftt_emit", 5.0 * npx, hipLaunchKernelGGL(gftt_emit_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
+    PickArgs p{};
+    p.keysA = t->sort.keysA; p.valsA = t->sort.valsA; p.valsB = t->sort.valsB; p.d_nbits = t->d_nbits; p.total = t->d_total;
+    p.w = w; p.h = h; p.max_corners = max_corners; p.cap = t->P.max_features; p.min_dist = t->P.min_dist;
+    p.out_xy = t->d_gftt_xy; p.out_n = t->d_out_n; p.ncand = t->d_ncand;
+    if (lds_form) {
+        LVI_LAUNCH(t->ctx, "gftt_sortpick", 0, hipLaunchKernelGGL(gftt_pick_kernel<true>, dim3(1), dim3(1024), 0, t->ctx.stream, p));
+    } else {
+        radix_sort_pairs(t->ctx, t->sort, t->d_n, t->d_nbits, 4, "gftt", 0.02 * npx);
+        LVI_LAUNCH(t->ctx, "gftt_pick", 0, hipLaunchKernelGGL(gftt_pick_kernel<false>, dim3(1), dim3(64), 0, t->ctx.stream, p));
+    }
+}
+}  // namespace
+
 int32_t lvi_tracker_run_gftt(lvi_tracker* t, int32_t max_corners)
 {
     if (!t || !t->have_forw) return tfail(LVI_ERR_STATE, "no image");
     return tguard(t, [&]() -> int32_t {
-        const int w = t->w, h = t->h, npx = w * h;
-        GfttArgs a{};
-        a.img = t->pyr[t->forw].lv[0].px; a.mask = t->have_mask ? t->d_mask : nullptr; a.w = w; a.h = h;
-        a.eig = t->d_eig; a.maxord = t->d_maxord; a.maxPartial = t->d_maxPartial; a.thr = t->d_thr; a.blockCnt = t->d_blockCnt; a.total = t->d_total;
-        a.keysA = t->sort.keysA; a.valsA = t->sort.valsA; a.d_n = t->d_n; a.d_nbits = t->d_nbits; a.quality = t->P.gftt_quality;
-        const int nblk = div_up(npx, CAND_TILE);
-        LVI_HIP(hipMemsetAsync(t->d_maxord, 0, sizeof(unsigned), t->ctx.stream));
-        LVI_LAUNCH(t->ctx, "gftt_mineig", 2.0 * npx + 4.0 * npx, hipLaunchKernelGGL(mineig_kernel, dim3(div_up(w, 32), div_up(h, 8)), dim3(256), 0, t->ctx.stream, a));
-        LVI_LAUNCH(t->ctx, "gftt_thr", 0, hipLaunchKernelGGL(gftt_thr_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, div_up(w, 32) * div_up(h, 8)));
-        LVI_LAUNCH(t->ctx, "gftt_count", 5.0 * npx, hipLaunchKernelGGL(gftt_count_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
-        LVI_LAUNCH(t->ctx, "gftt_scan", 0, hipLaunchKernelGGL(gftt_scan_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, nblk));
-        LVI_LAUNCH(t->ctx, "gftt_emit", 5.0 * npx, hipLaunchKernelGGL(gftt_emit_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
-        radix_sort_pairs(t->ctx, t->sort, t->d_n, t->d_nbits, 4, "gftt", 0.02 * npx);
-        PickArgs p{};
-        p.valsA = t->sort.valsA; p.valsB = t->sort.valsB; p.d_nbits = t->d_nbits; p.total = t->d_total;
-        p.w = w; p.h = h; p.max_corners = max_corners; p.cap = t->P.max_features; p.min_dist = t->P.min_dist;
-        p.out_xy = t->d_gftt_xy; p.out_n = t->d_out_n; p.ncand = t->d_ncand;
-        LVI_LAUNCH(t->ctx, "gftt_pick", 0, hipLaunchKernelGGL(gftt_pick_kernel, dim3(1), dim3(64), 0, t->ctx.stream, p));
         int res[2] = {0, 0};
-        LVI_HIP(hipMemcpyAsync(&res[0], t->d_out_n, sizeof(int), hipMemcpyDeviceToHost, t->ctx.stream));
-        LVI_HIP(hipMemcpyAsync(&res[1], t->d_ncand, sizeof(int), hipMemcpyDeviceToHost, t->ctx.stream));
-        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        for (int attempt = 0; attempt < 2; attempt++) {
+            enqueue_gftt(t, max_corners, attempt == 0 && !t->gftt_force_radix);
+            LVI_HIP(hipMemcpyAsync(&res[0], t->d_out_n, sizeof(int), hipMemcpyDeviceToHost, t->ctx.stream));
+            LVI_HIP(hipMemcpyAsync(&res[1], t->d_ncand, sizeof(int), hipMemcpyDeviceToHost, t->ctx.stream));
+            LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+            if (res[0] != -2) break;                        // -2: more candidates than the LDS form holds -> once more, radix form
+        }
+        t->gftt_pending = false;
         if (res[0] < 0) return tfail(LVI_ERR_CAPACITY, "more corners than the pick kernel's accepted-list capacity");
         if (res[0] > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "more corners than max_features");
         t->gftt_n = res[0]; t->gftt_ncand = res[1]; t->have_gftt = true;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_set_mask_circles(lvi_tracker* t, const float* centers_xy, int32_t n, int32_t radius)
+{
+    if (!t || n < 0 || (n > 0 && !centers_xy) || radius < 0 || radius > 120) return tfail(LVI_ERR_INVALID_ARG, "bad circle list");
+    if (!t->have_forw) return tfail(LVI_ERR_STATE, "no image");
+    if (n > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many circles");
+    return tguard(t, [&]() -> int32_t {
+        CircleArgs a{t->d_mask, t->w, t->h, t->d_centers, n, radius};
+        if (n) {
+            const int slot = (t->centers_slot ^= 1);
+            LVI_HIP(hipEventSynchronize(t->ev_centers[slot]));
+            std::memcpy(t->h_centers[slot], centers_xy, sizeof(float) * 2 * (size_t)n);
+            LVI_HIP(hipMemcpyAsync(t->d_centers, t->h_centers[slot], sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
+            LVI_HIP(hipEventRecord(t->ev_centers[slot], t->ctx.stream));
+        }
+        LVI_LAUNCH(t->ctx, "mask_fill", (double)t->w * t->h, hipLaunchKernelGGL(mask_fill_kernel, dim3(div_up(div_up(t->w * t->h, 16), 256)), dim3(256), 0, t->ctx.stream, a));
+        if (n) LVI_LAUNCH(t->ctx, "mask_circles", 0, hipLaunchKernelGGL(mask_circles_kernel, dim3(n), dim3(64), 0, t->ctx.stream, a));
+        t->have_mask = true;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_run_gftt_async(lvi_tracker* t, int32_t max_corners)
+{
+    if (!t || !t->have_forw) return tfail(LVI_ERR_STATE, "no image");
+    return tguard(t, [&]() -> int32_t {
+        enqueue_gftt(t, max_corners, !t->gftt_force_radix);
+        t->gftt_pending = true; t->gftt_pending_max = max_corners; t->have_gftt = false;
+        return LVI_OK;
+    });
+}
+
+int32_t lvi_tracker_finish_frame(lvi_tracker* t, const lvi_mei_params* cam, const float* kept_xy, int32_t n_kept,
+                                 float* new_xy, int32_t new_capacity, int32_t* n_new, float* un_xy)
+{
+    if (!t || n_kept < 0 || (n_kept > 0 && !kept_xy) || !n_new) return tfail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (n_kept > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many points");
+    return tguard(t, [&]() -> int32_t {
+        const int F = t->P.max_features;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const bool with_gftt = t->gftt_pending;
+            if (n_kept) {
+                const int slot = (t->pts_slot ^= 1);
+                LVI_HIP(hipEventSynchronize(t->ev_pts[slot]));
+                std::memcpy(t->h_pts[slot], kept_xy, sizeof(float) * 2 * (size_t)n_kept);
+                LVI_HIP(hipMemcpyAsync(t->d_un_in, t->h_pts[slot], sizeof(float) * 2 * n_kept, hipMemcpyHostToDevice, t->ctx.stream));
+                LVI_HIP(hipEventRecord(t->ev_pts[slot], t->ctx.stream));
+            }
+            int* d_hdr = reinterpret_cast<int*>(t->d_frame_out);
+            if (!with_gftt) LVI_HIP(hipMemsetAsync(t->d_out_n, 0, sizeof(int), t->ctx.stream));       // no new corners asked for
+            hipLaunchKernelGGL(frame_concat_kernel, dim3(1), dim3(64), 0, t->ctx.stream, t->d_un_in, n_kept, t->d_gftt_xy, t->d_out_n, F, t->d_all_xy, d_hdr + 2);
+            LVI_HIP(hipGetLastError());
+            if (cam) LVI_LAUNCH(t->ctx, "mei_undistort", 16.0 * F, hipLaunchKernelGGL(mei_undistort_kernel, dim3(div_up(F, 64)), dim3(64), 0, t->ctx.stream, *cam, t->d_all_xy, F,
+                                                                                       t->d_frame_out + 4 + 2 * (size_t)F, (const int*)(d_hdr + 2)));
+            LVI_HIP(hipMemcpyAsync(d_hdr, t->d_out_n, sizeof(int), hipMemcpyDeviceToDevice, t->ctx.stream));
+            LVI_HIP(hipMemcpyAsync(d_hdr + 1, t->d_ncand, sizeof(int), hipMemcpyDeviceToDevice, t->ctx.stream));
+            LVI_HIP(hipMemcpyAsync(t->d_frame_out + 4, t->d_gftt_xy, sizeof(float) * 2 * (size_t)F, hipMemcpyDeviceToDevice, t->ctx.stream));
+            LVI_HIP(hipMemcpyAsync(t->h_frame_out, t->d_frame_out, sizeof(float) * (4 + 4 * (size_t)F), hipMemcpyDeviceToHost, t->ctx.stream));   // the ONE read of the frame
+            LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+            const int* hdr = reinterpret_cast<const int*>(t->h_frame_out);
+            if (with_gftt && hdr[0] == -2 && attempt == 0) { enqueue_gftt(t, t->gftt_pending_max, false); continue; }   // beyond the LDS form: redo in the radix form
+            t->gftt_pending = false;
+            const int nn = with_gftt ? hdr[0] : 0;
+            if (nn < 0) return tfail(LVI_ERR_CAPACITY, "more corners than the pick kernel's accepted-list capacity");
+            if (nn > F || n_kept + nn > F) return tfail(LVI_ERR_CAPACITY, "more corners than max_features");
+            if (nn > new_capacity) return tfail(LVI_ERR_CAPACITY, "capacity too small");
+            *n_new = nn;
+            if (with_gftt) { t->gftt_n = nn; t->gftt_ncand = hdr[1]; t->have_gftt = true; }
+            if (nn && new_xy) std::memcpy(new_xy, t->h_frame_out + 4, sizeof(float) * 2 * (size_t)nn);
+            if (cam && un_xy) std::memcpy(un_xy, t->h_frame_out + 4 + 2 * (size_t)F, sizeof(float) * 2 * (size_t)(n_kept + nn));
+            return LVI_OK;
+        }
         return LVI_OK;
     });
 }
@@ -1025,6 +1212,10 @@ int32_t lvi_tracker_debug_get(lvi_tracker* t, int32_t what, void* dst, int64_t c
             case LVI_TDBG_GFTT_NCAND:
                 if (!t->have_gftt) return tfail(LVI_ERR_STATE, "GFTT not run");
                 host = true; host_val = t->gftt_ncand; bytes = 4;
+                break;
+            case LVI_TDBG_MASK:
+                if (!t->have_mask || !t->have_forw) return tfail(LVI_ERR_STATE, "no mask");
+                src = t->d_mask; bytes = (int64_t)t->w * t->h;
                 break;
             default: return tfail(LVI_ERR_INVALID_ARG, "unknown debug item");
         }

@@ -478,20 +478,50 @@ public:
         for (int i = 0; i < (int)v.size(); i++) if (status[i]) v[j++] = v[i];
         v.resize(j);
     }
-    void setMask()                                              // :36-69 (FISHEYE == 0)
+    // cv::circle(mask, pt, r, 0, -1) covers pixel (x, y) <=> |y - cy| <= r and |x - cx| <= hw[|y - cy|], hw = the widest horizontal span
+    // OpenCV's midpoint raster (FillCircle) draws at that row offset (fillCircleZero above draws exactly these spans)
+    static std::vector<int> circleHalfWidths(int radius)
     {
-        mask.assign((size_t)ROW * COL, 255);
+        std::vector<int> hw((size_t)radius + 1, -1);
+        int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+        while (dx >= dy) {
+            hw[dy] = std::max(hw[dy], dx); hw[dx] = std::max(hw[dx], dy);
+            dy++;
+            err += plus; plus += 2;
+            const int m = (err <= 0) - 1;
+            err -= minus & m; dx += m; minus -= m & 2;
+        }
+        return hw;
+    }
+    // :36-69 (FISHEYE == 0).  The order by track_cnt and the walk "keep a point if the mask is still 255 there, then blank MIN_DIST
+    // around it" stay on the host (150 points); "is the mask still 255 at (x, y)" is answered from the kept points' circles instead
+    // of a W x H image, and the image itself is rastered on the device from the kept points (lvi_tracker_set_mask_circles): nothing
+    // of its 0.6 - 0.9 MB crosses the bus.  `mask` (host image) is only materialised on request (keep_host_mask: tests).
+    bool keep_host_mask = false;
+    void setMask()
+    {
         std::vector<std::pair<int, std::pair<Point2f, int>>> cnt_pts_id;
         for (size_t i = 0; i < forw_pts.size(); i++) cnt_pts_id.push_back({track_cnt[i], {forw_pts[i], ids[i]}});
         std::sort(cnt_pts_id.begin(), cnt_pts_id.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
         forw_pts.clear(); ids.clear(); track_cnt.clear();
+        if (hw_.size() != (size_t)MIN_DIST + 1) hw_ = circleHalfWidths(MIN_DIST);
+        std::vector<std::pair<int, int>> kept_px;
         for (auto& it : cnt_pts_id) {
             const int x = cvRound(it.second.first.x), y = cvRound(it.second.first.y);   // Mat::at<uchar>(Point2f) → Point(cvRound)
             if (x < 0 || y < 0 || x >= COL || y >= ROW) continue;
-            if (mask[(size_t)y * COL + x] == 255) {
-                forw_pts.push_back(it.second.first); ids.push_back(it.second.second); track_cnt.push_back(it.first);
-                fillCircleZero(mask, COL, ROW, x, y, MIN_DIST);
+            bool free_px = true;
+            for (const auto& c : kept_px) {
+                const int ady = std::abs(y - c.second), adx = std::abs(x - c.first);
+                if (ady <= MIN_DIST && adx <= hw_[ady]) { free_px = false; break; }
             }
+            if (free_px) {
+                forw_pts.push_back(it.second.first); ids.push_back(it.second.second); track_cnt.push_back(it.first);
+                kept_px.push_back({x, y});
+            }
+        }
+        if (keep_host_mask) {
+            mask.assign((size_t)ROW * COL, 255);
+            for (const auto& c : kept_px) fillCircleZero(mask, COL, ROW, c.first, c.second, MIN_DIST);
         }
     }
     void addPoints()                                            // :71-79
@@ -576,21 +606,31 @@ public:
             reduceVector(ids, status); reduceVector(track_cnt, status);
         }
         for (auto& n : track_cnt) n++;                                                            // :150-151
+        bool gftt_asked = false;
         if (PUB_THIS_FRAME) {
             rejectWithF();                                                                        // :153
             setMask();
             const int n_max_cnt = MAX_CNT - (int)forw_pts.size();
             if (n_max_cnt > 0) {
-                std::vector<Point2f> out((size_t)t_.P.max_features);
-                int32_t n = 0;
-                check(lvi_tracker_set_mask(t_.get(), mask.data(), COL, ROW, COL), "lvi_tracker_set_mask");
-                check(lvi_tracker_run_gftt(t_.get(), n_max_cnt), "lvi_tracker_run_gftt");       // goodFeaturesToTrack (:166)
-                check(lvi_tracker_get_gftt(t_.get(), &out[0].x, (int32_t)out.size(), &n), "lvi_tracker_get_gftt");
-                n_pts.assign(out.begin(), out.begin() + n);
-            } else {
-                n_pts.clear();
+                // the mask is rastered on the device from the kept points; goodFeaturesToTrack (:166) is enqueued behind it
+                check(lvi_tracker_set_mask_circles(t_.get(), forw_pts.empty() ? nullptr : &forw_pts[0].x, (int32_t)forw_pts.size(), MIN_DIST), "lvi_tracker_set_mask_circles");
+                check(lvi_tracker_run_gftt_async(t_.get(), n_max_cnt), "lvi_tracker_run_gftt_async");
+                gftt_asked = true;
             }
-            addPoints();
+        }
+        // ONE read ends the frame: the new corners and — with a camera — the undistorted cur_pts of the next frame (= forw_pts + n_pts)
+        {
+            std::vector<Point2f> out((size_t)t_.P.max_features), un((size_t)t_.P.max_features);
+            int32_t n = 0;
+            const bool want_un = have_cam_;
+            if (gftt_asked || (want_un && !forw_pts.empty()))
+                check(lvi_tracker_finish_frame(t_.get(), want_un ? &cam_ : nullptr, forw_pts.empty() ? nullptr : &forw_pts[0].x, (int32_t)forw_pts.size(),
+                                               &out[0].x, (int32_t)out.size(), &n, want_un ? &un[0].x : nullptr), "lvi_tracker_finish_frame");
+            if (PUB_THIS_FRAME) {
+                n_pts.assign(out.begin(), out.begin() + (gftt_asked ? n : 0));
+                addPoints();
+            }
+            un_ready_.assign(un.begin(), un.begin() + (want_un ? forw_pts.size() : 0));
         }
         prev_pts = cur_pts;                                                                       // :200-204
         cur_pts = forw_pts;
@@ -601,7 +641,8 @@ public:
     {
         cur_un_pts.assign(cur_pts.size(), Point2f{0.f, 0.f});
         cur_un_pts_map.clear();
-        if (!cur_pts.empty())
+        if (un_ready_.size() == cur_pts.size()) cur_un_pts = un_ready_;                           // came back with the frame's one read (lvi_tracker_finish_frame)
+        else if (!cur_pts.empty())
             check(lvi_undistort_points(t_.get(), &cam_, &cur_pts[0].x, (int32_t)cur_pts.size(), &cur_un_pts[0].x), "lvi_undistort_points");
         for (size_t i = 0; i < cur_pts.size(); i++) cur_un_pts_map.insert({ids[i], cur_un_pts[i]});
         pts_velocity.clear();
@@ -632,6 +673,8 @@ private:
     TrackerHandle& t_;
     int ROW, COL, MAX_CNT, MIN_DIST;
     lvi_mei_params cam_{}; bool have_cam_ = false;
+    std::vector<int> hw_;                                      // circleHalfWidths(MIN_DIST)
+    std::vector<Point2f> un_ready_;                            // undistorted [forw_pts ; n_pts] of this frame, from lvi_tracker_finish_frame
 };
 
 // ---------------------------------------------------------------------------------------------- feature_tracker_node

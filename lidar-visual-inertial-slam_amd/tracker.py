@@ -128,6 +128,26 @@ class TrackerHotpath:
         self.lib.check(self.lib.dll.lvi_tracker_get_gftt(self._t, A._ptr(xy), cap, C.byref(n)), "lvi_tracker_get_gftt")
         return xy[:n.value].copy()
 
+    def set_mask_circles(self, centers_xy, radius):
+        """setMask's raster half (feature_tracker.cpp:64-66): mask = 255 with filled circles of `radius` around the points"""
+        c = np.ascontiguousarray(centers_xy, np.float32).reshape(-1, 2)
+        self.lib.check(self.lib.dll.lvi_tracker_set_mask_circles(self._t, A._ptr(c) if len(c) else None, len(c), int(radius)), "lvi_tracker_set_mask_circles")
+
+    def run_gftt_async(self, max_corners):
+        self.lib.check(self.lib.dll.lvi_tracker_run_gftt_async(self._t, int(max_corners)), "lvi_tracker_run_gftt_async")
+
+    def finish_frame(self, kept_xy, cam=None):
+        """the end of readImage in one read: (new corners of a pending run_gftt_async, undistorted [kept ; new] or None)"""
+        k = np.ascontiguousarray(kept_xy, np.float32).reshape(-1, 2)
+        cap = int(self.params.max_features)
+        new = np.zeros((cap, 2), np.float32)
+        un = np.zeros((cap, 2), np.float32)
+        n = C.c_int32(0)
+        c = A.MeiParams(*[float(cam[q]) for q in ("xi", "k1", "k2", "p1", "p2", "gamma1", "gamma2", "u0", "v0")]) if cam is not None else None
+        self.lib.check(self.lib.dll.lvi_tracker_finish_frame(self._t, C.byref(c) if c is not None else None, A._ptr(k) if len(k) else None, len(k),
+                                                             A._ptr(new), cap, C.byref(n), A._ptr(un) if c is not None else None), "lvi_tracker_finish_frame")
+        return new[:n.value].copy(), (un[:len(k) + n.value].copy() if c is not None else None)
+
     def sync(self):
         self.lib.check(self.lib.dll.lvi_tracker_sync(self._t), "lvi_tracker_sync")
 

@@ -375,7 +375,7 @@ struct lvi_tracker {
     std::vector<uint8_t> status;
     bool have_lk = false;
     std::vector<uint8_t> mask; bool have_mask = false;
-    std::vector<float> eig, gftt_xy; int gftt_n = 0, gftt_ncand = 0; bool have_gftt = false;
+    std::vector<float> eig, gftt_xy; int gftt_n = 0, gftt_ncand = 0; bool have_gftt = false, gftt_pending = false;
     bool equalize = false; double clahe_clip = 3.0; int clahe_tx = 8, clahe_ty = 8;       // EQUALIZE (feature_tracker.cpp:86-90)
 };
 
@@ -635,6 +635,63 @@ int32_t lvi_tracker_get_gftt(lvi_tracker* t, float* xy, int32_t capacity, int32_
     return LVI_OK;
 }
 
+// cv::circle(mask, pt, radius, 0, -1) as OpenCV's FillCircle rasterises it (imgproc/src/drawing.cpp): the midpoint recurrence,
+// horizontal spans clipped to the image (feature_tracker.cpp:64-66)
+static void fillCircleZeroMask(std::vector<uint8_t>& img, int w, int h, int cx, int cy, int radius)
+{
+    auto hline = [&](int y, int x0, int x1) {
+        if (y < 0 || y >= h) return;
+        x0 = std::max(x0, 0); x1 = std::min(x1, w - 1);
+        for (int x = x0; x <= x1; x++) img[(size_t)y * w + x] = 0;
+    };
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        hline(cy - dy, cx - dx, cx + dx); hline(cy + dy, cx - dx, cx + dx);
+        hline(cy - dx, cx - dy, cx + dy); hline(cy + dx, cx - dy, cx + dy);
+        dy++;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+int32_t lvi_tracker_set_mask_circles(lvi_tracker* t, const float* centers_xy, int32_t n, int32_t radius)
+{
+    if (!t || n < 0 || (n > 0 && !centers_xy) || radius < 0 || radius > 120) return tfail(LVI_ERR_INVALID_ARG, "bad circle list");
+    if (!t->have_forw) return tfail(LVI_ERR_STATE, "no image");
+    if (n > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many circles");
+    const int w = t->forwPyr[0].w, h = t->forwPyr[0].h;
+    t->mask.assign((size_t)w * h, 255);
+    for (int i = 0; i < n; i++) fillCircleZeroMask(t->mask, w, h, cvRound(centers_xy[2 * i]), cvRound(centers_xy[2 * i + 1]), radius);
+    t->have_mask = true;
+    return LVI_OK;
+}
+int32_t lvi_tracker_run_gftt_async(lvi_tracker* t, int32_t max_corners)
+{
+    const int32_t st = lvi_tracker_run_gftt(t, max_corners);
+    if (st == LVI_OK) t->gftt_pending = true;
+    return st;
+}
+int32_t lvi_tracker_finish_frame(lvi_tracker* t, const lvi_mei_params* cam, const float* kept_xy, int32_t n_kept,
+                                 float* new_xy, int32_t new_capacity, int32_t* n_new, float* un_xy)
+{
+    if (!t || n_kept < 0 || (n_kept > 0 && !kept_xy) || !n_new) return tfail(LVI_ERR_INVALID_ARG, "bad arguments");
+    if (n_kept > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many points");
+    const int nn = t->gftt_pending ? t->gftt_n : 0;
+    t->gftt_pending = false;
+    if (n_kept + nn > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "more corners than max_features");
+    if (nn > new_capacity) return tfail(LVI_ERR_CAPACITY, "capacity too small");
+    *n_new = nn;
+    if (nn && new_xy) std::memcpy(new_xy, t->gftt_xy.data(), sizeof(float) * 2 * (size_t)nn);
+    if (cam && un_xy) {
+        for (int i = 0; i < n_kept; i++) mei_undistort(*cam, kept_xy[2 * i], kept_xy[2 * i + 1], un_xy[2 * i], un_xy[2 * i + 1]);
+        for (int i = 0; i < nn; i++) mei_undistort(*cam, t->gftt_xy[2 * i], t->gftt_xy[2 * i + 1], un_xy[2 * (n_kept + i)], un_xy[2 * (n_kept + i) + 1]);
+    }
+    return LVI_OK;
+}
+
 int32_t lvi_lk_track(lvi_tracker* t, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h, int32_t stride,
                      const float* prev_xy, int32_t n, float* next_xy, uint8_t* status, float* err)
 {
@@ -681,6 +738,10 @@ int32_t lvi_tracker_debug_get(lvi_tracker* t, int32_t what, void* dst, int64_t c
         case LVI_TDBG_GFTT_NCAND:
             if (!t->have_gftt) return tfail(LVI_ERR_STATE, "GFTT not run");
             src = &t->gftt_ncand; bytes = sizeof(int32_t);
+            break;
+        case LVI_TDBG_MASK:
+            if (!t->have_mask || !t->have_forw) return tfail(LVI_ERR_STATE, "no mask");
+            src = t->mask.data(); bytes = (int64_t)t->mask.size();
             break;
         default: return tfail(LVI_ERR_INVALID_ARG, "unknown debug item");
     }

@@ -266,3 +266,76 @@ def test_lk_float_accumulator_variant_report(pkg, oracle, hip):
     assert rep["flip_rate"] < 5e-3, rep
     assert rep["p99_dpos_px"] < 1e-2, rep
     o.close(); g.close()
+
+
+def test_mask_from_circles_sortpick_and_one_read_frame_end(pkg, oracle, hip, frames, monkeypatch):
+    """round 3, the tracker node path (feature_tracker.cpp:36-69, 153-205): (a) the mask rastered on the device from the kept points
+    equals the oracle's cv::circle raster and an independent numpy restatement of the midpoint spans, byte for byte, for points inside,
+    on and beyond the border; (b) goodFeaturesToTrack with that mask: the one-workgroup LDS sort + pick gives the corners of the
+    12-launch radix form (LVI_GFTT_RADIX=1) and of the oracle, also with thousands of candidates and equal values (a tiled image);
+    (c) lvi_tracker_finish_frame returns, in one read, the new corners and the undistorted [kept ; new] points of separate calls."""
+    A = pkg._abi
+    w, h = frames["w"], frames["h"]
+    rng = np.random.default_rng(5)
+    kept = np.concatenate([np.stack([rng.uniform(-10, w + 10, 60), rng.uniform(-10, h + 10, 60)], axis=1),
+                           np.array([[0.0, 0.0], [w - 1.0, h - 1.0], [w / 2 + 0.5, h / 2 - 0.5], [19.5, 20.5], [w - 20.0, 5.49]])]).astype(np.float32)
+
+    def numpy_mask(r):
+        hw = np.full(r + 1, -1)
+        err, dx, dy, plus, minus = 0, r, 0, 1, 2 * r - 1
+        while dx >= dy:
+            hw[dy] = max(hw[dy], dx); hw[dx] = max(hw[dx], dy)
+            dy += 1; err += plus; plus += 2
+            m = (1 if err <= 0 else 0) - 1
+            err -= minus & m; dx += m; minus -= m & 2
+        img = np.full((h, w), 255, np.uint8)
+        for (x, y) in kept:
+            cx, cy = int(np.rint(x)), int(np.rint(y))
+            for j in range(-r, r + 1):
+                yy = cy + j
+                x0, x1 = max(cx - hw[abs(j)], 0), min(cx + hw[abs(j)], w - 1)
+                if 0 <= yy < h and hw[abs(j)] >= 0 and x1 >= x0:
+                    img[yy, x0:x1 + 1] = 0
+        return img
+
+    cam = dict(xi=1.40630886, k1=-0.03678799, k2=0.2610374, p1=0.00144626, p2=0.00035872, gamma1=1454.59041, gamma2=1451.94369, u0=0.5 * w, v0=0.5 * h)
+    tiled = np.tile(frames["img0"][:64, :64], (h // 64 + 1, w // 64 + 1))[:h, :w].copy()      # periodic: many exactly equal min-eigenvalues
+    for img, radius, quota in ((frames["img0"], 20, 150), (frames["img0"], 7, 0), (tiled, 3, 0)):
+        res = {}
+        for name, lib, env in (("oracle", oracle, None), ("lds", hip, None), ("radix", hip, "1")):
+            if env:
+                monkeypatch.setenv("LVI_GFTT_RADIX", env)
+            else:
+                monkeypatch.delenv("LVI_GFTT_RADIX", raising=False)
+            t = pkg.TrackerHotpath(lib, max_width=w, max_height=h, max_features=4096 if quota == 0 else 1024)
+            t.params.min_dist = float(radius)
+            t.close(); t = pkg.TrackerHotpath(lib, params=t.params)
+            t.push_image(img)
+            t.set_mask_circles(kept, radius)
+            t.run_gftt_async(quota)
+            inside = kept[(kept[:, 0] >= 0) & (kept[:, 0] < w) & (kept[:, 1] >= 0) & (kept[:, 1] < h)]
+            new, un = t.finish_frame(inside, cam)
+            mask = t.debug_get(A.TDBG_MASK, np.uint8).reshape(h, w)
+            ncand = int(t.debug_get(A.TDBG_GFTT_NCAND, np.int32)[0])
+            # the same through the separate calls
+            t.run_gftt(quota)
+            sep = t.get_gftt()
+            un_sep = t.undistort_points(cam, np.concatenate([inside, new])) if len(inside) + len(new) <= int(t.params.max_features) else None
+            res[name] = (mask, new, un, sep, un_sep, ncand)
+            t.close()
+        monkeypatch.delenv("LVI_GFTT_RADIX", raising=False)
+        want = numpy_mask(radius)
+        for name in ("oracle", "lds", "radix"):
+            mask, new, un, sep, un_sep, ncand = res[name]
+            np.testing.assert_array_equal(mask, want)
+            np.testing.assert_array_equal(new, res["oracle"][1])
+            np.testing.assert_array_equal(new, sep)
+            ok = ~np.isnan(un)
+            np.testing.assert_array_equal(np.isnan(un), np.isnan(res["oracle"][2]))
+            np.testing.assert_array_equal(bits(un)[ok], bits(res["oracle"][2])[ok])
+            if un_sep is not None:
+                np.testing.assert_array_equal(bits(un)[ok], bits(un_sep)[ok])
+            assert ncand == res["oracle"][5]
+        assert (want[np.rint(res["lds"][1][:, 1]).astype(int), np.rint(res["lds"][1][:, 0]).astype(int)] == 255).all()
+        if img is tiled:
+            assert res["lds"][5] > 2000            # thousands of candidates, ties included
