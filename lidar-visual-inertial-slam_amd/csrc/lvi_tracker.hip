@@ -579,6 +579,7 @@ struct PickArgs {
     const unsigned *valsA, *valsB; const int* d_nbits; const int* total;
     int w, h, max_corners, cap; double min_dist;
     float* out_xy; int* out_n; int* ncand;
+    long long* dbg;                  // [8] phase stamps of the LDS form (diagnostics; may be null)
 };
 
 // sequential minimum-distance selection (featureselect.cpp), one wavefront, ballot-resolved.  A candidate is compared with
@@ -586,119 +587,191 @@ struct PickArgs {
 // accepted indices each in LDS (corners at least min_dist apart: two fit a cell), so a candidate reads a handful of entries
 // instead of walking all accepted corners; a fifth corner in one cell, or a grid beyond the LDS budget, falls back to that walk.
 // SORTLDS = false: the candidates arrive sorted (12-launch radix sort), one wavefront picks.
-// SORTLDS = true (at most GFTT_LDS_MAX candidates — a 1280 x 720 frame has a few thousand): ONE workgroup of 1024 threads sorts
-// the (value, address) keys in LDS (bitonic; the keys are unique: ~value bits, then ~address, i.e. descending value, higher
-// address first among equal values — cv::goodFeaturesToTrack's greaterThanPtr order) and its first wavefront picks from LDS:
-// one launch instead of thirteen.  The host chooses by the candidate count's bound; gftt_sortpick_kernel exits when the count
-// exceeds the LDS capacity and the radix path runs instead (a.use_lds tells the two apart on the device).
-constexpr int GFTT_LDS_MAX = 8192;
+// SORTLDS = true: ONE workgroup of 1024 threads.  The greedy pick consumes candidates in descending value order and stops at the
+// quota (MAX_CNT - tracked: tens of corners), so only the strongest few thousand are ever looked at: the workgroup takes a
+// 1024-bin histogram of the values, cuts a band of at most GFTT_BAND candidates off its top, sorts THAT band in LDS (bitonic;
+// keys = ~value bits, then ~address: descending value, higher address first among equal values — cv::goodFeaturesToTrack's
+// greaterThanPtr order — and unique), lets its first wavefront pick from it, and goes on to the next band only if the quota is
+// not met.  One launch instead of thirteen; any number of candidates.  A value bin that alone exceeds the band (thousands of
+// exactly equal values) or an accepted list beyond the LDS tables reports -2: the host runs the radix form for that frame.
+constexpr int GFTT_BAND = 1024;                   // one candidate per thread: the band is ordered by counting, for every key, the keys below it
 template <bool SORTLDS>
 __global__ __launch_bounds__(SORTLDS ? 1024 : 64) void gftt_pick_kernel(PickArgs a)
 {
     constexpr int ACC_MAX = SORTLDS ? 2048 : 4096, GRID_MAX = SORTLDS ? 4096 : 8192, CELL_CAP = 4;
+    constexpr int NT = SORTLDS ? 1024 : 64;
     __shared__ short ax[ACC_MAX], ay[ACC_MAX], acx[ACC_MAX], acy[ACC_MAX];      // accepted corners and their grid cells (no division in the inner loop)
     __shared__ unsigned char gcnt[GRID_MAX];
     __shared__ unsigned short gent[GRID_MAX * CELL_CAP];
-    __shared__ unsigned long long skey[SORTLDS ? GFTT_LDS_MAX : 1];
+    __shared__ unsigned long long band[SORTLDS ? GFTT_BAND : 1];
+    __shared__ unsigned hist[SORTLDS ? 1024 : 1], hsub[SORTLDS ? 8 * 1024 : 1];      // hsub: eight copies (lane & 7) — weak candidates crowd the last bins
+    __shared__ int ws[NT / 64 + 1];
+    __shared__ unsigned s_kmin, s_kmax;
+    __shared__ int s_lo, s_hi, s_state;                   // the band's bin range [lo, hi); 0 = go on | 1 = finished | 2 = redo in the radix form
     const int total = *a.total;
-    if (SORTLDS) {
-        if (total > GFTT_LDS_MAX) { if (threadIdx.x == 0) { *a.out_n = -2; *a.ncand = total; } return; }      // the host runs the radix form for this frame
-        int N = 64;
-        while (N < total) N <<= 1;
-        for (int i = threadIdx.x; i < N; i += 1024)
-            skey[i] = i < total ? (((unsigned long long)a.keysA[i] << 32) | (unsigned long long)(0xFFFFFFFFu - a.valsA[i])) : ~0ull;
-        __syncthreads();
-        for (int k = 2; k <= N; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int p = threadIdx.x; p < (N >> 1); p += 1024) {
-                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), q = i | j;
-                    const unsigned long long x = skey[i], y = skey[q];
-                    if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[q] = x; }
-                }
-                __syncthreads();
-            }
-        if (threadIdx.x >= 64) return;
-    } else {
-    }
     const unsigned* vals = rs_result_in_B(a.d_nbits[0]) ? a.valsB : a.valsA;
-    auto cand = [&](int i) -> unsigned { return SORTLDS ? 0xFFFFFFFFu - (unsigned)skey[i] : vals[i]; };
     const int l = threadIdx.x;
-    if (l == 0) *a.ncand = total;
+    if (l == 0) { *a.ncand = total; s_state = 0; s_lo = 0; s_hi = 0; s_kmin = 0xFFFFFFFFu; s_kmax = 0u; }
     const bool filter = a.min_dist >= 1.0;
     const int cell = filter ? (int)rint(a.min_dist) : 1;
     const double md2 = a.min_dist * a.min_dist;
     const int gw = (a.w + cell - 1) / cell, gh = (a.h + cell - 1) / cell;
     bool grid = filter && gw * gh <= GRID_MAX;
-    if (grid) for (int c = l; c < gw * gh; c += 64) gcnt[c] = 0;
-    if (SORTLDS) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
+    if (grid) for (int c = l; c < gw * gh; c += NT) gcnt[c] = 0;
+    if (SORTLDS) for (int b = l; b < 8 * 1024; b += NT) hsub[b] = 0u;
+    __syncthreads();
+    int shift = 0;
+    long long tq[6] = {0, 0, 0, 0, 0, 0}; int nbands = 0;
+    if (SORTLDS && l == 0) tq[0] = clock64();
+    if (SORTLDS) {
+        // range of the value keys, then the histogram (keys ascend as values descend: bin 0 holds the strongest)
+        unsigned kmn = 0xFFFFFFFFu, kmx = 0u;
+        for (int i = l; i < total; i += NT) { const unsigned k = a.keysA[i]; kmn = min(kmn, k); kmx = max(kmx, k); }
+        atomicMin(&s_kmin, kmn); atomicMax(&s_kmax, kmx);
+        __syncthreads();
+        while (((s_kmax - s_kmin) >> shift) >= 1024u) shift++;
+        for (int i = l; i < total; i += NT) atomicAdd(&hsub[(l & 7) * 1024 + ((a.keysA[i] - s_kmin) >> shift)], 1u);
+        __syncthreads();
+        { unsigned v = 0u;
+#pragma unroll
+          for (int c = 0; c < 8; c++) v += hsub[c * 1024 + l];
+          // inclusive prefix over the bins (thread = bin): hist[b] = candidates in bins 0 .. b
+          int tot; const int ex = block_excl_scan<1024>((int)v, ws, &tot); hist[l] = (unsigned)ex + v; }
+        __syncthreads();
+        if (l == 0) tq[1] = clock64();
+    }
     int nacc = 0;
     // one corner past the capacity is enough to know the result does not fit (it is counted, not stored)
     const int limit = (a.max_corners > 0) ? min(a.max_corners, a.cap + 1) : a.cap + 1;
     bool overflow = false;
-    unsigned pnext = l < total ? cand(l) : 0u;             // the next batch's candidates are in flight while this one is resolved
-    for (int base = 0; base < total && nacc < limit; base += 64) {
-        const int i = base + l;
-        bool alive = i < total;
-        int x = 0, y = 0;
-        const int p = (int)pnext;
-        pnext = i + 64 < total ? cand(i + 64) : 0u;
-        if (alive) { y = p / a.w; x = p - y * a.w; }
-        const int xc = x / cell, yc = y / cell;
-        if (alive && filter) {
-            if (grid) {
-                for (int dyc = -1; dyc <= 1 && alive; dyc++) {
-                    const int cy = yc + dyc;
-                    if (cy < 0 || cy >= gh) continue;
-                    for (int dxc = -1; dxc <= 1 && alive; dxc++) {
-                        const int cx = xc + dxc;
-                        if (cx < 0 || cx >= gw) continue;
-                        const int c = cy * gw + cx, n = gcnt[c];
-                        for (int e = 0; e < n; e++) {
-                            const int k = gent[c * CELL_CAP + e];
+    for (;;) {
+        int count = total;                                   // the radix form: one "band" = every candidate, already in order
+        if (SORTLDS) {
+            // the next band: bins [lo, hi) with at most GFTT_BAND candidates, at least one bin (thread = bin, hist = inclusive prefix)
+            {
+                const int lo = s_hi;                              // (read by every thread before thread 0 rewrites it below the barrier)
+                const unsigned before = lo > 0 ? hist[lo - 1] : 0u;
+                const bool fits = l >= lo && hist[l] - before <= (unsigned)GFTT_BAND;
+                const unsigned long long mk = __ballot(fits);     // bins are monotone: the fitting ones form a prefix of [lo, 1024)
+                if ((l & 63) == 0) ws[l >> 6] = __popcll(mk);
+                __syncthreads();
+                if (l == 0) {
+                    int nfit = 0;
+                    for (int q = 0; q < NT / 64; q++) nfit += ws[q];
+                    int hi = lo + nfit;
+                    if (total == 0 || lo >= 1024) s_state = 1;
+                    else if (nfit == 0) { hi = lo + 1; s_state = 2; }     // one bin of (nearly) equal values is larger than the band
+                    s_lo = lo; s_hi = hi;
+                }
+            }
+            __syncthreads();
+            if (s_state) break;
+            const unsigned lo = (unsigned)s_lo, hi = (unsigned)s_hi;
+            const unsigned before = lo > 0 ? hist[lo - 1] : 0u;      // candidates in the bins above this band's
+            if (l == 0) tq[2] -= clock64();
+            nbands += l == 0 ? 1 : 0;
+            // counting sort by bin (the bins ARE value order): a key goes to its bin's segment of the band, any place inside it …
+            for (unsigned b = lo + (unsigned)l; b < hi; b += NT) hsub[b] = 0u;          // (hsub[0 .. 1024) serves as the bins' cursors now)
+            __syncthreads();
+            for (int i = l; i < total; i += NT) {
+                const unsigned k = a.keysA[i], b = (k - s_kmin) >> shift;
+                if (b >= lo && b < hi) {
+                    const unsigned seg = (b > 0 ? hist[b - 1] : 0u) - before;
+                    band[seg + atomicAdd(&hsub[b], 1u)] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - a.valsA[i]);
+                }
+            }
+            __syncthreads();
+            count = (int)(hist[hi - 1] - before);
+            {   // … and is then ranked among the few keys of its own bin (unique keys: the count of smaller ones is its place)
+                unsigned long long mine = ~0ull; int place = 0;
+                if (l < count) {
+                    mine = band[l];
+                    const unsigned b = ((unsigned)(mine >> 32) - s_kmin) >> shift;
+                    const int s0 = (int)((b > 0 ? hist[b - 1] : 0u) - before), s1 = (int)(hist[b] - before);
+                    int r = 0;
+                    for (int j = s0; j < s1; j++) r += band[j] < mine ? 1 : 0;
+                    place = s0 + r;
+                }
+                __syncthreads();
+                if (l < count) band[place] = mine;
+                __syncthreads();
+            }
+            if (l == 0) { const long long t = clock64(); tq[2] += t; tq[3] -= t; }
+        }
+        if (l < 64) {
+            auto cand = [&](int i) -> unsigned { return SORTLDS ? 0xFFFFFFFFu - (unsigned)band[i] : vals[i]; };
+            unsigned pnext = l < count ? cand(l) : 0u;       // the next batch's candidates are in flight while this one is resolved
+            for (int base = 0; base < count && nacc < limit; base += 64) {
+                const int i = base + l;
+                bool alive = i < count;
+                int x = 0, y = 0;
+                const int p = (int)pnext;
+                pnext = i + 64 < count ? cand(i + 64) : 0u;
+                if (alive) { y = p / a.w; x = p - y * a.w; }
+                const int xc = x / cell, yc = y / cell;
+                if (alive && filter) {
+                    if (grid) {
+                        for (int dyc = -1; dyc <= 1 && alive; dyc++) {
+                            const int cy = yc + dyc;
+                            if (cy < 0 || cy >= gh) continue;
+                            for (int dxc = -1; dxc <= 1 && alive; dxc++) {
+                                const int cx = xc + dxc;
+                                if (cx < 0 || cx >= gw) continue;
+                                const int c = cy * gw + cx, n = gcnt[c];
+                                for (int e = 0; e < n; e++) {
+                                    const int k = gent[c * CELL_CAP + e];
+                                    const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
+                                    if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
+                                }
+                            }
+                        }
+                    } else {
+                        for (int k = 0; k < nacc; k++) {
+                            const int dxc = acx[k] - xc, dyc = acy[k] - yc;
+                            if (dxc < -1 || dxc > 1 || dyc < -1 || dyc > 1) continue;
                             const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
                             if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
                         }
                     }
                 }
-            } else {
-                for (int k = 0; k < nacc; k++) {
-                    const int dxc = acx[k] - xc, dyc = acy[k] - yc;
-                    if (dxc < -1 || dxc > 1 || dyc < -1 || dyc > 1) continue;
-                    const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
-                    if ((double)(dx * dx + dy * dy) < md2) { alive = false; break; }
+                uint64_t m = __ballot(alive);
+                while (m && nacc < limit) {
+                    const int first = __ffsll((long long)m) - 1;
+                    const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);      // `first` is wave-uniform: scalar reads
+                    const int fxc = __builtin_amdgcn_readlane(xc, first), fyc = __builtin_amdgcn_readlane(yc, first);
+                    if (grid) {                                     // same for every lane: the cell of the accepted corner takes its index
+                        const int c = fyc * gw + fxc, n = gcnt[c];
+                        if (n < CELL_CAP && nacc < ACC_MAX) { if (l == first) { gent[c * CELL_CAP + n] = (unsigned short)nacc; gcnt[c] = (unsigned char)(n + 1); } }
+                        else grid = false;                          // from here on: the walk over all accepted corners
+                    }
+                    if (l == first) {
+                        if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; acx[nacc] = (short)xc; acy[nacc] = (short)yc; }
+                        if (nacc < a.cap) { a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y; }
+                        alive = false;
+                    }
+                    nacc++;
+                    if (alive && filter) {
+                        const int dxc = fxc - xc, dyc = fyc - yc;
+                        if (dxc >= -1 && dxc <= 1 && dyc >= -1 && dyc <= 1) {
+                            const float dx = (float)(x - fx), dy = (float)(y - fy);
+                            if ((double)(dx * dx + dy * dy) < md2) alive = false;
+                        }
+                    }
+                    m = __ballot(alive);
+                    if (nacc >= ACC_MAX && filter) { overflow = true; break; }
                 }
+                if (overflow) break;
+                __threadfence_block(); __builtin_amdgcn_wave_barrier();      // one wavefront: its LDS operations complete in order
             }
+            if (SORTLDS && l == 0) tq[3] += clock64();
+            if (SORTLDS && l == 0 && (overflow || nacc >= limit)) s_state = overflow ? 2 : 1;
         }
-        uint64_t m = __ballot(alive);
-        while (m && nacc < limit) {
-            const int first = __ffsll((long long)m) - 1;
-            const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);      // `first` is wave-uniform: scalar reads
-            const int fxc = __builtin_amdgcn_readlane(xc, first), fyc = __builtin_amdgcn_readlane(yc, first);
-            if (grid) {                                     // same for every lane: the cell of the accepted corner takes its index
-                const int c = fyc * gw + fxc, n = gcnt[c];
-                if (n < CELL_CAP && nacc < ACC_MAX) { if (l == first) { gent[c * CELL_CAP + n] = (unsigned short)nacc; gcnt[c] = (unsigned char)(n + 1); } }
-                else grid = false;                          // from here on: the walk over all accepted corners
-            }
-            if (l == first) {
-                if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; acx[nacc] = (short)xc; acy[nacc] = (short)yc; }
-                if (nacc < a.cap) { a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y; }
-                alive = false;
-            }
-            nacc++;
-            if (alive && filter) {
-                const int dxc = fxc - xc, dyc = fyc - yc;
-                if (dxc >= -1 && dxc <= 1 && dyc >= -1 && dyc <= 1) {
-                    const float dx = (float)(x - fx), dy = (float)(y - fy);
-                    if ((double)(dx * dx + dy * dy) < md2) alive = false;
-                }
-            }
-            m = __ballot(alive);
-            if (nacc >= ACC_MAX && filter) { overflow = true; break; }
-        }
-        if (overflow) break;
-        if (SORTLDS) { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } else __syncthreads();
+        if (!SORTLDS) break;
+        __syncthreads();
+        if (s_state) break;
     }
-    if (l == 0) *a.out_n = overflow ? (SORTLDS ? -2 : -1) : nacc;      // (the LDS form's accepted list is half the radix form's: -2 = redo there)
+    if (l == 0) *a.out_n = SORTLDS ? (s_state == 2 ? -2 : nacc) : (overflow ? -1 : nacc);
+    if (SORTLDS && l == 0 && a.dbg) { a.dbg[0] = tq[1] - tq[0]; a.dbg[1] = tq[2]; a.dbg[2] = tq[3]; a.dbg[3] = clock64() - tq[0]; a.dbg[4] = nbands; a.dbg[5] = total; a.dbg[6] = nacc; }
 }
 
 int32_t tfail(int32_t code, const std::string& msg) { set_error(msg); return code; }
@@ -732,6 +805,7 @@ struct lvi_tracker {
     float* d_frame_out = nullptr;      // [4 + 2 F + 2 F] one block: {n_new, n_cand, n_all, 0}, the new corners, the undistorted points of [kept ; new]
     float* h_frame_out = nullptr;      // pinned mirror
     float* d_all_xy = nullptr;         // [2 F] kept ++ new
+    long long* d_dbg = nullptr;        // [8] phase stamps of gftt_sortpick (LVI_TDBG_SORTPICK_CYCLES)
     // f-2 / f-3
     uint8_t *d_eq = nullptr, *d_lut = nullptr; float *d_un_in = nullptr, *d_un_out = nullptr;
     bool equalize = false; double clahe_clip = 3.0; int clahe_tx = 8, clahe_ty = 8;
@@ -784,6 +858,7 @@ void tracker_layout(AR& ar, lvi_tracker& t)
     t.d_un_in = ar.template alloc<float>(2 * (size_t)F); t.d_un_out = ar.template alloc<float>(2 * (size_t)F);
     t.d_centers = ar.template alloc<float>(2 * (size_t)F); t.d_all_xy = ar.template alloc<float>(2 * (size_t)F);
     t.d_frame_out = ar.template alloc<float>(4 + 4 * (size_t)F);
+    t.d_dbg = ar.template alloc<long long>(8);
 }
 
 // src (w x h, dense) → dst equalised; both device buffers of the handle
@@ -1047,7 +1122,7 @@ void enqueue_gftt(lvi_tracker* t, int32_t max_corners, bool lds_form)
     PickArgs p{};
     p.keysA = t->sort.keysA; p.valsA = t->sort.valsA; p.valsB = t->sort.valsB; p.d_nbits = t->d_nbits; p.total = t->d_total;
     p.w = w; p.h = h; p.max_corners = max_corners; p.cap = t->P.max_features; p.min_dist = t->P.min_dist;
-    p.out_xy = t->d_gftt_xy; p.out_n = t->d_out_n; p.ncand = t->d_ncand;
+    p.out_xy = t->d_gftt_xy; p.out_n = t->d_out_n; p.ncand = t->d_ncand; p.dbg = t->d_dbg;
     if (lds_form) {
         LVI_LAUNCH(t->ctx, "gftt_sortpick", 0, hipLaunchKernelGGL(gftt_pick_kernel<true>, dim3(1), dim3(1024), 0, t->ctx.stream, p));
     } else {
@@ -1212,6 +1287,9 @@ int32_t lvi_tracker_debug_get(lvi_tracker* t, int32_t what, void* dst, int64_t c
             case LVI_TDBG_GFTT_NCAND:
                 if (!t->have_gftt) return tfail(LVI_ERR_STATE, "GFTT not run");
                 host = true; host_val = t->gftt_ncand; bytes = 4;
+                break;
+            case 7:                                  // phase stamps of gftt_sortpick (diagnostics, HIP only)
+                src = t->d_dbg; bytes = 64;
                 break;
             case LVI_TDBG_MASK:
                 if (!t->have_mask || !t->have_forw) return tfail(LVI_ERR_STATE, "no mask");
