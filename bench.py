@@ -88,20 +88,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    # LVI_BENCH_DEVICE=cpu: the CPU tier's rehearsal of THIS control flow (tests/test_distributed_gloo.py: two gloo ranks, the
+    # library handle replaced by the test): tensors on the host, no CUDA calls.  Never set by the driver.
+    on_gpu = os.environ.get("LVI_BENCH_DEVICE", "cuda") != "cpu"
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda unavailable)")
     # rehearsal switches for a ONE-GPU box (the N > 1 code path with gloo, every rank on cuda:0); never set by the driver
     rehearse = os.environ.get("LVI_BENCH_REHEARSE_ON_ONE_GPU") == "1"
     if rehearse:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+
+    def dev_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
+        if rehearse or not on_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev)          # RCCL
     pkg = graft.import_package()
     A, S, R = pkg._abi, pkg.synth, pkg.replay
     hip = pkg.load_hip()                      # raises when the HIP library is missing: no fallback
@@ -113,7 +123,8 @@ def main():
              map_on_main_stream=(1 if B * NB >= 4 else 0) if args.map_stream < 0 else args.map_stream,   # one stream per hardware queue once >= 4 scans are in flight
              max_keyframes=(args.keyframes + 8) if args.map_source == "assemble" else 0,
              max_keyframe_points=(args.map_points + 200000) if args.map_source == "assemble" else 0)
-    hs = [pkg.LidarHotpath(hip, device=local_rank, **P) for _ in range(B)]
+    dev_index = local_rank if on_gpu else 0
+    hs = [pkg.LidarHotpath(hip, device=dev_index, **P) for _ in range(B)]
     g = hs[0]
 
     # ---------------------------------------------------------------- frozen local map: rank 0 builds, RCCL broadcasts
@@ -133,7 +144,7 @@ def main():
     if world > 1:
         dist.broadcast(d_mc, 0)
         dist.broadcast(d_ms, 0)
-    torch.cuda.synchronize()
+    dev_sync()
     keys = None
     if args.map_source == "assemble":
         # SURVEY f-4: the local map is not handed over as one raw cloud but fused on the device, per step, from the
@@ -164,7 +175,7 @@ def main():
     # ---------------------------------------------------------------- measured copy ceiling of this GPU (report % of the vendor
     # figure AND of a measured device copy): 256 MB float4 tensor copied device-to-device, bytes read + written / time
     copy_gbs = None
-    if rank == 0:
+    if rank == 0 and on_gpu:
         src = torch.empty((16 * 1024 * 1024, 4), dtype=torch.float32, device=dev).normal_()
         dst = torch.empty_like(src)
         for _ in range(3):
@@ -190,7 +201,7 @@ def main():
     total = n_prime + args.warmup + n_windows * args.steps + args.profile_steps
     per_step = B * NB                                                 # scans per step and rank
     d_rec = torch.zeros((total * per_step, 8), dtype=torch.float32, device=dev)
-    torch.cuda.synchronize()
+    dev_sync()
     setup_s = time.time() - t_setup
 
     enq = [0.0]
@@ -227,10 +238,10 @@ def main():
     roll = R.RollingReplay(hs, issue, gather, depth=args.queue_depth)
 
     def fence():
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     step0 = 0
     if n_prime:
@@ -286,7 +297,7 @@ def main():
     tracker_out = None
     if not args.no_tracker:
         try:
-            tracker_out = bench_tracker(pkg, hip, local_rank, rank, world, args.tracker_seconds)
+            tracker_out = bench_tracker(pkg, hip, dev_index, rank, world, args.tracker_seconds)
         except Exception as e:                      # noqa: BLE001 — the tracker leg must not hide the headline
             tracker_out = dict(error=str(e), value=0.0)
         if world > 1:                               # outside the try: every rank issues this collective, whatever its leg did
@@ -300,7 +311,7 @@ def main():
     seq_out = None
     if args.sequential_scans > 0 and rank == 0:
         try:
-            seq_out = bench_sequential(pkg, hip, local_rank, dev, args.sequential_scans, args.n_raw, args.keyframes, args.kf_n_raw)
+            seq_out = bench_sequential(pkg, hip, local_rank if on_gpu else 0, dev, args.sequential_scans, args.n_raw, args.keyframes, args.kf_n_raw)
         except Exception as e:                      # noqa: BLE001
             seq_out = dict(error=str(e))
 
@@ -471,7 +482,7 @@ def main():
         for h in hs:
             h.close()
         P2 = dict(P); P2["map_plan_cache"] = 1
-        hs2 = [pkg.LidarHotpath(hip, device=local_rank, **P2) for _ in range(B)]
+        hs2 = [pkg.LidarHotpath(hip, device=dev_index, **P2) for _ in range(B)]
         for b, h in enumerate(hs2):
             if b == 0 or args.no_share_map:
                 h.map_upload_device(d_mc.data_ptr(), nc, d_ms.data_ptr(), ns)
@@ -482,11 +493,11 @@ def main():
         w2 = max(args.warmup, 3) + min(n_prime, 40)            # fresh handles: the runtime's one-off stall is primed away again
         for i in range(w2):
             roll2.step(i)
-        roll2.flush(); torch.cuda.synchronize()
+        roll2.flush(); dev_sync()
         t0 = time.perf_counter()
         for i in range(args.cached_plan_steps):
             roll2.step(w2 + i)
-        roll2.flush(); torch.cuda.synchronize()
+        roll2.flush(); dev_sync()
         el2 = time.perf_counter() - t0
         out["value_cached_plan"] = dict(scans_per_sec=round(per_step * args.cached_plan_steps / el2, 2), steps=args.cached_plan_steps, this_rank_only=True,
                                         note="lvi_lidar_params.map_plan_cache = 1: bounding box, per-bin counts and partition offsets of the raw map computed once "

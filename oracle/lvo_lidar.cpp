@@ -1135,9 +1135,12 @@ int32_t lvi_scan_batch_get_records(lvi_lidar* h, int32_t n_scans, lvi_pose_recor
 int32_t lvi_batch_select(lvi_lidar* h, int32_t slot) { return (h && slot == 0) ? LVI_OK : fail(LVI_ERR_UNSUPPORTED, "hip only: the oracle keeps the intermediates of the last scan only"); }
 
 int32_t lvi_scan_match_async(lvi_lidar*, const float*, void*) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
-int32_t lvi_scan_upload_device(lvi_lidar*, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
+int32_t lvi_scan_upload_device(lvi_lidar* h, const void* d_pts, int32_t n_raw) { return lvi_scan_upload(h, static_cast<const lvi_livox_pt*>(d_pts), n_raw); }   // "device" memory of the CPU oracle is host memory
 int32_t lvi_scan_replay_enqueue(lvi_lidar*, const void*, int32_t, const float*, void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
-int32_t lvi_map_upload_device(lvi_lidar*, const void*, int32_t, const void*, int32_t) { return fail(LVI_ERR_UNSUPPORTED, "hip only"); }
+int32_t lvi_map_upload_device(lvi_lidar* h, const void* c, int32_t nc, const void* s, int32_t ns)
+{
+    return lvi_map_upload(h, static_cast<const lvi_pt*>(c), nc, static_cast<const lvi_pt*>(s), ns);          // "device" memory of the CPU oracle is host memory
+}
 // the HIP library aliases the owner's clouds; here they are copied (the same clouds, the same results)
 int32_t lvi_map_share(lvi_lidar* h, lvi_lidar* owner)
 {

@@ -210,3 +210,46 @@ def test_rolling_replay_bookkeeping(pkg):
     assert R.shard_frames(10, 1, 4) == [1, 5, 9]
     assert sorted(sum((R.shard_frames(40, r, 8) for r in range(8)), [])) == list(range(40))
     assert [R.scan_index(1, 1, z, 2, 4, 8) for z in range(4)] == [4, 5, 6, 7]
+
+
+BENCH_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import __graft_entry__ as graft
+from oracle import loader
+pkg = graft.import_package()
+ora = loader.load(pkg)
+pkg.load_hip = lambda: ora                      # the TEST puts the CPU oracle where bench.py loads the HIP library (bench.py itself never touches oracle/
+                                                # outside its cpu_baseline leg); what runs is bench.py's own main(): broadcast, windows, gathers, tracker gather
+os.environ["LVI_BENCH_DEVICE"] = "cpu"
+import bench
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--prime-steps", "2", "--profile-steps", "1",
+            "--n-raw", "5001", "--keyframes", "5", "--kf-n-raw", "5001", "--map-points", "20000", "--pool", "3", "--inflight", "2", "--batch", "2",
+            "--icp-iters", "6", "--no-cpu", "--tracker-seconds", "0.05", "--sequential-scans", "0", "--cached-plan-steps", "2"]
+bench.main()
+"""
+
+
+def test_bench_main_two_ranks_gloo(tmp_path):
+    """bench.py's OWN main() for world = 2 — map broadcast, priming by step count, timed windows with the
+    barrier fences, per-step gather of the pose records (odd step count), tracker-rate gather, the cached-plan secondary figure —
+    over gloo with oracle-backed handles.  The RCCL form of the same collectives has never executed anywhere."""
+    import json
+    port = _free_port()
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER % dict(root=ROOT))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path)))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-3000:] for o in outs)
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]      # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["metric"] == "scans_per_sec_100k_mid360" and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["scans_per_step"] == 2 * 2 * 2 and d["config"]["map_plan"] == "per-rebuild"
+    assert d["value"] > 0 and len(d["value_windows"]["scans_per_sec"]["all"]) == 2
+    assert d["results_ok"] is True, d["pose_err_vs_truth"]
+    assert len(d["tracker"]["per_rank"]) == 2 and d["tracker"]["value"] > 0
+    assert d["value_cached_plan"]["scans_per_sec"] > 0
