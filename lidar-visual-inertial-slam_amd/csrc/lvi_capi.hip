@@ -61,6 +61,7 @@ struct lvi_lidar {
     int sel = 0;                                    // slot the fetch / inspection entry points read (lvi_batch_select)
     LidarDev& cur() { return *slots[sel]; }
     std::vector<int32_t> vkeys, vcells, vcounts;    // debug of the last lvi_voxel_downsample
+    bool vdbg_pending = false; int vdbg_n = 0;      // … not fetched yet (lvi_debug_get does it)
     bool have_icp_host = false;
     lvi_lidar* share_owner = nullptr;               // lvi_map_share: the handle whose raw map this one reads
     std::atomic<int> shared_by{0};                  // handles that read this one's raw map (they may live on other host threads): it must not change while > 0
@@ -115,6 +116,13 @@ int read_int(LidarDev& d, const int* p)
     return v;
 }
 
+int32_t dev_status_code(int st)
+{
+    if (st & DEV_ERR_SECTOR_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "a ring sector exceeds FEAT_SEG_CAP points (Horizon_SCAN too large for the LDS-resident sector kernel)");
+    if (st & DEV_ERR_SECTOR_HANDOVER) return fail(LVI_ERR_HIP, "sector kernel: a workgroup never received its predecessor's hand-over word");
+    if (st & DEV_ERR_GRID_TOO_LARGE) return fail(LVI_ERR_CAPACITY, "local map extent too large for the KNN grid");
+    return LVI_OK;
+}
 int32_t check_dev_status(LidarDev& d)
 {
     int w[2] = {0, 0};
@@ -461,12 +469,13 @@ int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi
         LidarDev& d = h->cur();
         set_pose_init(d, pose);
         stage_scan_match_enqueue(d, imu, nullptr);
-        int nq[3] = {0, 0, 0};
+        int nq[3] = {0, 0, 0}, dw[2] = {0, 0};
         d2h(d, d.h_icp, d.icp, 1);
         d2h(d, nq, d.voxScan.d_nout, 3);
+        d2h(d, dw, d.d_status, 2);                                    // the device status words ride along: one wait per scan
         sync(d);
         h->have_icp_host = true;
-        int32_t st = check_dev_status(d); if (st) return st;
+        int32_t st = dev_status_code(dw[0] | dw[1]); if (st) return st;
         const IcpState& s = *d.h_icp;
         memset(out, 0, sizeof(*out));
         out->status = s.status; out->iters = s.iters; out->converged = s.converged;
@@ -856,18 +865,22 @@ int32_t lvi_voxel_downsample(lvi_lidar* h, const lvi_pt* in, int32_t n, float le
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         h2d(d, d.genIn, in, (size_t)n);
-        VoxSegStatic st{d.genIn, nullptr, d.genOut, leaf};
-        d.voxGen.set_static(d.ctx, &st);
-        VoxSegDyn dyn{0, n};
-        h2d(d, d.voxGen.d_dyn, &dyn, 1);
-        sync(d);
+        if (!d.gen_static_set || d.gen_leaf != leaf) {               // (the segment table is uploaded once per leaf size: the node calls this with one leaf for every scan)
+            VoxSegStatic st{d.genIn, nullptr, d.genOut, leaf};
+            d.voxGen.set_static(d.ctx, &st);
+            d.gen_static_set = true; d.gen_leaf = leaf;
+        }
+        d.voxGen.n_host[0] = n; d.voxGen.use_n_host = true;          // the length travels as a kernel argument
         voxel_downsample_batch(d.ctx, d.voxGen, "gen", n);
-        const int m = read_int(d, d.voxGen.d_nout);
-        *n_out = m;
-        voxel_debug_fetch(d.ctx, d.voxGen, n, h->vkeys, h->vcells, h->vcounts);
-        if (m > out_capacity) return fail(LVI_ERR_CAPACITY, "voxel output capacity too small");
-        d2h(d, out, d.genOut, (size_t)m);
+        // ONE wait: the count and (at most the caller's capacity of) the output travel together
+        const int fetch = std::min(n, out_capacity);
+        int m = 0;
+        d2h(d, &m, d.voxGen.d_nout, 1);
+        if (fetch > 0) d2h(d, out, d.genOut, (size_t)fetch);
         sync(d);
+        *n_out = m;
+        h->vdbg_pending = true; h->vdbg_n = n;                       // LVI_DBG_VOXEL_*: fetched when asked for (until the next call that uses the generic buffers)
+        if (m > out_capacity) return fail(LVI_ERR_CAPACITY, "voxel output capacity too small");
         return LVI_OK;
     });
 }
@@ -902,6 +915,7 @@ int32_t lvi_transform_cloud(lvi_lidar* h, const lvi_pt* in, int32_t n, const flo
     if (n > h->d.voxGen.seg_cap) return fail(LVI_ERR_CAPACITY, "n exceeds capacity");
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
+        h->vdbg_pending = false;
         h2d(d, d.genIn, in, (size_t)n);
         transform_cloud(d, d.genIn, n, pose6, d.genOut);
         d2h(d, out, d.genOut, (size_t)n);
@@ -957,9 +971,9 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
                 std::vector<long long> v(8); d2h(d, v.data(), d.d_feat_cycles, 8); sync(d);
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
-            case LVI_DBG_VOXEL_KEYS: return dbg_out(h->vkeys, 0, dst, cap, n_bytes);
-            case LVI_DBG_VOXEL_CELLS: return dbg_out(h->vcells, 0, dst, cap, n_bytes);
-            case LVI_DBG_VOXEL_COUNTS: return dbg_out(h->vcounts, 0, dst, cap, n_bytes);
+            case LVI_DBG_VOXEL_KEYS: case LVI_DBG_VOXEL_CELLS: case LVI_DBG_VOXEL_COUNTS:
+                if (h->vdbg_pending) { voxel_debug_fetch(h->d.ctx, h->d.voxGen, h->vdbg_n, h->vkeys, h->vcells, h->vcounts); h->vdbg_pending = false; }
+                return dbg_out(what == LVI_DBG_VOXEL_KEYS ? h->vkeys : (what == LVI_DBG_VOXEL_CELLS ? h->vcells : h->vcounts), 0, dst, cap, n_bytes);
             case LVI_DBG_ICP_JTJ: {
                 if (!h->have_icp_host) return fail(LVI_ERR_STATE, "scan_match not run");
                 std::vector<float> v(d.h_icp->jtj, d.h_icp->jtj + 27 * d.h_icp->iters);

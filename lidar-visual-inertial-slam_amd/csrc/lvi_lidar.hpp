@@ -129,6 +129,7 @@ struct LidarDev {
     // stage flags (host)
     bool have_raw = false, have_org = false, have_feat = false, have_ds = false, have_map_raw = false, have_map = false;
     bool gen_valid = false; int gen_n = 0;
+    bool gen_static_set = false; float gen_leaf = 0.f;     // lvi_voxel_downsample: the segment table on the device is for this leaf size
     // ---- f-4: incremental local map (lvi_map_update); slot 0 of a non-batch handle only
     IncMap inc;
     bool inc_ready = false;                                // tables hold exactly inc_mult's keyframes at inc_pose's poses

@@ -631,27 +631,46 @@ __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
     for (int b = threadIdx.x; b < nbins; b += 256) row[b] = cnt[b];
 }
 
-// per bin: exclusive prefix over the workgroups (in place) and the bin's total
+// per bin: exclusive prefix over the workgroups (in place) and the bin's total.  64 bins x 4 quarters of the workgroup range per
+// workgroup of this kernel: a quarter's column is summed (loads 8 deep), the quarters meet in LDS, then each writes its prefixes
+// (one column walked by ONE thread was 512 dependent steps: 65 us for eight slots)
 __global__ __launch_bounds__(256) void vb_colscan_kernel(Batch<VoxArgs> B_)
 {
     const VoxArgs& a = B_.a[blockIdx.z];
     unsigned* totals = a.binCountOut;
     const int s = blockIdx.y;
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= VB_NB) return;
+    const int b = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;     // 4 parts of VB_WG / 4 workgroups each
+    constexpr int PW = VB_WG / 4;
+    __shared__ unsigned psum[4][64];
+    const bool live = b < VB_NB && b < a.grid[s].nbins;
+    unsigned* col = a.wprefix + (size_t)s * VB_WG * VB_NB + (live ? b : 0);
     unsigned acc = 0u;
-    if (b < a.grid[s].nbins) {
-        unsigned* col = a.wprefix + (size_t)s * VB_WG * VB_NB + b;
-        for (int w0 = 0; w0 < VB_WG; w0 += 8) {
+    if (live) {
+        for (int w0 = part * PW; w0 < (part + 1) * PW; w0 += 8) {
             unsigned v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) v[u] = col[(size_t)(w0 + u) * VB_NB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { col[(size_t)(w0 + u) * VB_NB] = acc; acc += v[u]; }
+            for (int u = 0; u < 8; u++) acc += v[u];
         }
     }
-    totals[(size_t)s * VB_NB + b] = acc;
-    if (b == 0 && a.plan_spec) a.planMiss[s] = 0;      // consumed (vox_setup read it): the next run's vb_plan starts clean
+    psum[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    unsigned before = 0u, total = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const unsigned t = psum[q][threadIdx.x & 63]; before += q < part ? t : 0u; total += t; }
+    if (live) {
+        unsigned run = before;
+        for (int w0 = part * PW; w0 < (part + 1) * PW; w0 += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = col[(size_t)(w0 + u) * VB_NB];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { col[(size_t)(w0 + u) * VB_NB] = run; run += v[u]; }
+        }
+    }
+    if (part == 0 && b < VB_NB) totals[(size_t)s * VB_NB + b] = live ? total : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.plan_spec) a.planMiss[s] = 0;      // consumed (vox_setup read it): the next run's vb_plan starts clean
 }
 
 __global__ __launch_bounds__(256) void vb_scatter_det_kernel(Batch<VoxArgs> B_)
@@ -1464,7 +1483,7 @@ void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& p, const char* tag, double
     if (voxel_resolve_mode(p) == VOX_BINNED && p.d_binCountCached) {
         LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, 1), dim3(64), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[2], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_w_kernel, dim3(VB_WG, p.nseg, 1), dim3(256), 0, ctx.stream, B));
-        hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 256, p.nseg, 1), dim3(256), 0, ctx.stream, B);
+        hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 64, p.nseg, 1), dim3(256), 0, ctx.stream, B);
         LVI_HIP(hipGetLastError());
         p.hist_cached = true;
     }
@@ -1523,7 +1542,7 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
         LVI_LAUNCH(ctx, "vb_plan/map", 16.0 * n_hint, hipLaunchKernelGGL(vb_plan_kernel, dim3(VB_WG, p.nseg, S), dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, S), dim3(64), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, "vb_hist_w/map", 0, hipLaunchKernelGGL(vb_hist_w_kernel, dim3(VB_WG, p.nseg, S), dim3(256), 0, ctx.stream, B));
-        LVI_LAUNCH(ctx, "vb_colscan/map", 0, hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 256, p.nseg, S), dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, "vb_colscan/map", 0, hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 64, p.nseg, S), dim3(256), 0, ctx.stream, B));
     } else {
         for (int z = 0; z < S; z++) B.a[z].plan_spec = 0;
         if (!cached) LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, S), dim3(256), 0, ctx.stream, B));
