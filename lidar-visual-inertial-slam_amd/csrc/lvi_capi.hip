@@ -276,6 +276,7 @@ void lvi_lidar_destroy(lvi_lidar* h)
     for (int s = 0; s < LVI_LIDAR_MARKS; s++) if (d.evMark[s]) (void)hipEventDestroy(d.evMark[s]);
     if (d.evMain) (void)hipEventDestroy(d.evMain);
     if (d.evMap) (void)hipEventDestroy(d.evMap);
+    if (d.evMapDeps) (void)hipEventDestroy(d.evMapDeps);
     delete h;
 }
 
@@ -468,21 +469,30 @@ int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->cur();
         set_pose_init(d, pose);
-        stage_scan_match_enqueue(d, imu, nullptr);
         int nq[3] = {0, 0, 0}, dw[2] = {0, 0};
-        d2h(d, d.h_icp, d.icp, 1);
-        d2h(d, nq, d.voxScan.d_nout, 3);
-        d2h(d, dw, d.d_status, 2);                                    // the device status words ride along: one wait per scan
-        sync(d);
+        // With the reference's break rule (:1325-1337) the loop usually ends after 3 - 6 of its <= 20 iterations, and a launch that
+        // finds the loop over still costs its dispatch: the iterations go out in chunks of six, each followed by the finish step,
+        // and the host looks at the state before it sends the next chunk (the finish step leaves the loop state alone).
+        const int max_it = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS);
+        const int chunk = d.P.icp_disable_break ? std::max(max_it, 1) : 6;
+        for (int it0 = 0;; it0 += chunk) {
+            const int it1 = std::min(it0 + chunk, max_it);
+            stage_scan_match_enqueue(d, imu, nullptr, it0, it1);
+            d2h(d, d.h_icp, d.icp, 1);
+            d2h(d, nq, d.voxScan.d_nout, 3);
+            d2h(d, dw, d.d_status, 2);                                // the device status words ride along: one wait per chunk
+            sync(d);
+            if (it1 >= max_it || d.h_icp->done || d.h_icp->status != LVI_OK || (dw[0] | dw[1])) break;
+        }
         h->have_icp_host = true;
         int32_t st = dev_status_code(dw[0] | dw[1]); if (st) return st;
         const IcpState& s = *d.h_icp;
         memset(out, 0, sizeof(*out));
-        out->status = s.status; out->iters = s.iters; out->converged = s.converged;
+        out->status = s.final_status; out->iters = s.iters; out->converged = s.converged;
         out->degenerate = s.degenerate; out->n_corner_ds = nq[0]; out->n_surf_ds = nq[1];
         for (int i = 0; i < LVI_ICP_MAX_ITERS; i++) out->n_sel[i] = s.n_sel[i];
         for (int k = 0; k < 6; k++) { out->pose[k] = s.final_pose[k]; pose[k] = s.final_pose[k]; }
-        return s.status;
+        return s.final_status;
     });
 }
 
@@ -733,6 +743,7 @@ int32_t lvi_keyframe_add_current(lvi_lidar* h, const float pose[6], int32_t* ind
         int32_t st = kf_reserve(h, nq[0], nq[1]); if (st) return st;
         if (nq[0]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used, q.cornerDS, sizeof(lvi_pt) * (size_t)nq[0], hipMemcpyDeviceToDevice, d.ctx.stream));
         if (nq[1]) LVI_HIP(hipMemcpyAsync(d.kfPool + d.kf_pool_used + nq[0], q.surfDS, sizeof(lvi_pt) * (size_t)nq[1], hipMemcpyDeviceToDevice, d.ctx.stream));
+        mark_map_deps(d);                                             // a later map update reads these clouds on the second stream
         return kf_commit(h, nq[0], nq[1], pose, index_out);
     });
 }

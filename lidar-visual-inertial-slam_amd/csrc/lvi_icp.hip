@@ -815,8 +815,12 @@ __device__ void q_to_rpy(const Quatd& q, double& roll, double& pitch, double& ya
 __device__ void icp_finish_body(const IcpArgs& a)
 {
     IcpState& s = *a.st;
-    float* T = s.pose[s.cur & 1].T;
-    const bool ran = (s.status == LVI_OK);
+    // (works on copies: the loop state stays as it is, so that a caller that enqueues the loop in chunks — lvi_scan_match with
+    // the reference's break rule — can go on after looking at this record)
+    float T[6];
+    for (int k = 0; k < 6; k++) T[k] = s.pose[s.cur & 1].T[k];
+    int status = s.status;
+    const bool ran = (status == LVI_OK);
     if (ran) {
         for (int k = 0; k < 6; k++) s.pose_trace[s.iters * 6 + k] = T[k];
         if (a.imu_available && fabsf(a.imu_pitch) < 1.4f) {                       // transformUpdate :1347-1367
@@ -829,14 +833,15 @@ __device__ void icp_finish_body(const IcpArgs& a)
         T[0] = fminf(fmaxf(T[0], -a.rot_tol), a.rot_tol);                         // :1370-1372
         T[1] = fminf(fmaxf(T[1], -a.rot_tol), a.rot_tol);
         T[5] = fminf(fmaxf(T[5], -a.z_tol), a.z_tol);
-        if (!s.any_lm) s.status = LVI_TOO_FEW_CORRESPONDENCES;
+        if (!s.any_lm) status = LVI_TOO_FEW_CORRESPONDENCES;
     }
     // a device-side error of the stages that fed this scan match (sector capacity, KNN grid size) travels in the record:
     // the async / replay entry points have no other channel back to the caller
     const int dev = a.d_status[0] | a.d_status[1];
-    if (dev) s.status = (dev & DEV_ERR_SECTOR_HANDOVER) ? LVI_ERR_HIP : LVI_ERR_CAPACITY;
+    if (dev) status = (dev & DEV_ERR_SECTOR_HANDOVER) ? LVI_ERR_HIP : LVI_ERR_CAPACITY;
     for (int k = 0; k < 6; k++) { s.final_pose[k] = T[k]; s.record.pose[k] = T[k]; }
-    s.record.status = s.status; s.record.iters = s.iters;
+    s.final_status = status;
+    s.record.status = status; s.record.iters = s.iters;
     if (a.d_record) *reinterpret_cast<lvi_pose_record*>(a.d_record) = s.record;
 }
 // ------------------------------------------------------------------------------------------- the 6 x 6 end of an iteration, on ONE wavefront
@@ -1528,6 +1533,15 @@ IcpArgs icp_args(LidarDev& d)
 
 }  // namespace
 
+// everything enqueued on the main stream so far must finish before a later local-map update (second stream) touches the map
+// buffers or reads the keyframe store
+void mark_map_deps(LidarDev& d)
+{
+    if (!d.evMapDeps) LVI_HIP(hipEventCreateWithFlags(&d.evMapDeps, hipEventDisableTiming));
+    LVI_HIP(hipEventRecord(d.evMapDeps, d.ctx.stream));
+    d.have_map_deps = true;
+}
+
 void join_map(LidarDev& d)
 {
     if (d.map_pending) { LVI_HIP(hipStreamWaitEvent(d.ctx.stream, d.evMap, 0)); d.map_pending = false; }
@@ -1629,8 +1643,10 @@ bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys)
     const Ctx& cx = d.P.map_on_main_stream ? d.ctx : d.ctx2;
     const bool forked = cx.stream != d.ctx.stream;
     if (forked) {
-        LVI_HIP(hipEventRecord(d.evMain, d.ctx.stream));            // the previous scan's GN loop still reads the previous index
-        LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMain, 0));
+        // What the update must wait for on the main stream: the previous scan's GN loop (it reads the index this update rewrites)
+        // and the keyframe copies into the store — recorded where they were enqueued (mark_map_deps).  NOT the stages of the
+        // CURRENT scan already in that stream (organise, sector kernel, the scan's grids): the update runs beside them.
+        if (d.have_map_deps) LVI_HIP(hipStreamWaitEvent(cx.stream, d.evMapDeps, 0));
     }
     const int nkf = (int)d.kf_pose.size();
     std::vector<int> want(nkf, 0);
@@ -1751,7 +1767,7 @@ void set_pose_init(const Slots& sl, const float* p, bool clear_status)
 }
 void set_pose_init(LidarDev& d, const float p[6]) { set_pose_init(OneSlot(d).s, p, false); }
 
-void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_records)
+void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_records, int it_begin, int it_end)
 {
     LidarDev& d = sl.first();
     join_map(d);
@@ -1771,7 +1787,8 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
     const IcpArgs& a = B.a[0];
     const unsigned S = (unsigned)sl.n;
     const Ctx& cx = d.ctx;
-    for (int it = 0; it < a.max_iters; it++) {
+    const int it_last = it_end < 0 ? a.max_iters : std::min(it_end, a.max_iters);
+    for (int it = it_begin; it < it_last; it++) {
         // (the grid covers ext_cap features; the ~1 200 workgroups beyond the actual count exit at once — measured: launching
         // exactly the occupied 360 instead changes nothing)
         // iteration 0 searches the unit ball; later iterations search the (much smaller) ball of the previous neighbours, where
@@ -1801,9 +1818,10 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
             else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
         }
     }
-    LVI_LAUNCH(cx, "icp_final", 0, hipLaunchKernelGGL(icp_final_kernel, dim3(1, 1, S), dim3(64), 0, cx.stream, B, a.max_iters));
+    LVI_LAUNCH(cx, "icp_final", 0, hipLaunchKernelGGL(icp_final_kernel, dim3(1, 1, S), dim3(64), 0, cx.stream, B, it_last));
+    if (sl.n == 1 && !d.P.map_on_main_stream) mark_map_deps(d);     // (the GN loop read the index)
 }
-void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record) { stage_scan_match_enqueue(OneSlot(d).s, imu, d_record); }
+void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record, int it_begin, int it_end) { stage_scan_match_enqueue(OneSlot(d).s, imu, d_record, it_begin, it_end); }
 
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd)
 {

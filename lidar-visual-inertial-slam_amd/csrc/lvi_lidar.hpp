@@ -29,6 +29,7 @@ struct IcpState {                        // device, one per handle
     IcpPose scratch;                     // lvi_transform_cloud / lvi_debug_residuals
     int done;                            // LMOptimization returned true (and break enabled) or loop skipped
     int converged, degenerate, iters, any_lm, status;
+    int final_status;                    // what the scan's record says (status + LVI_TOO_FEW_CORRESPONDENCES / device errors), written by the finish step
     int n_sel[LVI_ICP_MAX_ITERS];
     float jtj[LVI_ICP_MAX_ITERS * 27];
     float pose_trace[(LVI_ICP_MAX_ITERS + 1) * 6];
@@ -50,6 +51,7 @@ struct LidarDev {
     Ctx ctx;                                               // scan-side stages and the GN loop
     Ctx ctx2;                                              // map build (independent of the scan until scan matching)
     hipEvent_t evMain = nullptr, evMap = nullptr;
+    hipEvent_t evMapDeps = nullptr; bool have_map_deps = false;   // main-stream work a later incremental map update (second stream) must wait for (mark_map_deps)
     hipEvent_t evMark[LVI_LIDAR_MARKS] = {};               // lvi_lidar_mark / lvi_lidar_wait_mark, created on first use
     bool map_pending = false;                              // map build enqueued on ctx2, not yet joined by ctx
     Profiler prof;
@@ -156,7 +158,8 @@ void stage_organize(const Slots& s);
 void stage_extract(const Slots& s);
 void stage_downsample(const Slots& s);
 void stage_map_build(const Slots& s);
-void stage_scan_match_enqueue(const Slots& s, const lvi_imu_hint* imu, void* d_records);   // slot z writes its record to d_records + 32 z (when not null)
+// Gauss-Newton iterations [it_begin, it_end) (it_end < 0: to icp_max_iters) followed by the finish step; slot z writes its record to d_records + 32 z (when not null)
+void stage_scan_match_enqueue(const Slots& s, const lvi_imu_hint* imu, void* d_records, int it_begin = 0, int it_end = -1);
 void set_pose_init(const Slots& s, const float* pose_init, bool clear_status);          // [n][6]; clear_status: also zero the scan-side device status words
 bool stage_map_update(LidarDev& d, const int32_t* keys, int n_keys);       // f-4 incremental: false = not applicable / device said no → the caller assembles
 void stage_map_index(const Slots& s, const Ctx& cx);                     // the KNN grid index over every slot's DS map
@@ -167,8 +170,9 @@ void stage_downsample(LidarDev& d);
 // lvi_icp.hip
 void stage_map_build(LidarDev& d);
 void join_map(LidarDev& d);                                // make the main stream wait for a pending map build
+void mark_map_deps(LidarDev& d);                           // record: a later map update on the second stream waits for everything enqueued on the main stream so far
 void set_pose_init(LidarDev& d, const float pose_init[6]);  // enqueue: d_pose_init <- pose_init
-void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record);   // starts from d_pose_init
+void stage_scan_match_enqueue(LidarDev& d, const lvi_imu_hint* imu, void* d_record, int it_begin = 0, int it_end = -1);   // starts from d_pose_init
 void debug_knn(LidarDev& d, int which, const lvi_pt* d_queries, int nq, int* d_idx, float* d_sqd);
 void debug_residuals(LidarDev& d, int which, const float pose[6]);
 void transform_cloud(LidarDev& d, const lvi_pt* d_in, int n, const float pose6[6], lvi_pt* d_out);

@@ -274,8 +274,10 @@ public:
         timeLastProcessing = timeLaserInfoCur;
         lastProcessed = true;
         updateInitialGuess(ci);
-        extractSurroundingKeyFrames();
+        // downsampleCurrentScan (:987-999) is enqueued BEFORE extractSurroundingKeyFrames: the two do not depend on each other, and
+        // the scan's grids then run on the main stream while the local map is updated on the handle's second stream
         check(lvi_scan_downsample(h_.get()), "lvi_scan_downsample");
+        extractSurroundingKeyFrames();
         lastStatus = check(lvi_scan_match(h_.get(), &imu, transformTobeMapped, &last), "lvi_scan_match");
         saveKeyFramesAndFactor();
         return true;
