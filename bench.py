@@ -329,7 +329,7 @@ def main():
     Q = cnt["corner_ds"] + cnt["surf_ds"]
     for s in stats:
         s["avg_us"] = 1e3 * s["total_ms"] / max(s["launches"], 1)
-        if s["name"] == "icp_residual":
+        if s["name"] == "icp_gn":
             # the library books a nominal 128 * 0.25 * n_raw per scan; the real query count is known here (read back above)
             s["bytes_alg"] = 128.0 * Q * NB * s["launches"]
         s["gbs"] = round((s["bytes_alg"] / s["launches"]) / (s["avg_us"] * 1e-6) / 1e9, 1) if s["bytes_alg"] > 0 else None
@@ -363,9 +363,11 @@ def main():
     if with_bytes:
         # dominant kernel = largest total time per step among the kernels of the path
         roofline = roof(with_bytes[0], "HIP events on the launch stream of one of the handles, profiled pass of the same workload right "
-                                       "after the timed windows; the kernel with the largest total time per step.  icp_residual is a chain of "
-                                       "dependent gathers on L2s that every launch finds cold (clock64 phase stamps, DESIGN.md 5), neither HBM- nor "
-                                       "VALU-bound: its HBM fraction is small by construction; bytes = 128 B x the real query count read back from the device")
+                                       "after the timed windows, three other handles launching beside it; the kernel with the largest total time per step.  "
+                                       "icp_gn (one Gauss-Newton iteration: end of the previous iteration + searches + fits + rows) is a chain of dependent "
+                                       "gathers on L2s that every launch finds cold plus ~2 000 instructions of small-matrix code per wavefront (clock64 phase "
+                                       "stamps, DESIGN.md 5): neither HBM- nor VALU-bound, its HBM fraction is small by construction; bytes = 128 B x the real "
+                                       "query count read back from the device")
         stream = max(with_bytes, key=lambda s: s["bytes_alg"] / s["launches"] if s["avg_us"] > 0 else 0)
         big = [s for s in with_bytes if s["bytes_alg"] / s["launches"] >= 0.5 * stream["bytes_alg"] / stream["launches"]]
         roofline_bw = roof(max(big, key=lambda s: s["total_ms"]), "the HBM-streaming kernel with the largest total time (map re-voxelisation)")
