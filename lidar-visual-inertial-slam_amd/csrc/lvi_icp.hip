@@ -14,10 +14,10 @@
 // 1 m" for the rest.
 // Distances are ((dx*dx)+dy*dy)+dz*dz in f32 without FMA, as FLANN's L2_Simple computes them.
 //
-// The Gauss-Newton loop never returns to the host: the 27 sums of AtA/AtB are reduced in double
-// (cv::gemm accumulates f32 products in double) to per-workgroup partials, summed in fixed order
-// by a one-wave solve kernel that also does the 6x6 QR solve, the iteration-0 eigen analysis,
-// the pose update and the convergence test, and prepares the next iteration's transform.
+// The Gauss-Newton loop never returns to the host, one launch per iteration: the 27 sums of AtA/AtB are formed in double
+// (cv::gemm accumulates f32 products in double) per 16 features, turned into exact fixed point and added to sharded
+// accumulators; the NEXT launch reads the totals and every workgroup runs the 6x6 end of the iteration (QR solve, the
+// iteration-0 eigen analysis, pose update, convergence test) on them — no exchange inside a launch.
 #include <cstdlib>
 
 #include "lvi_lidar.hpp"
