@@ -1175,10 +1175,8 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
     __shared__ __attribute__((aligned(16))) float srow[QPB][8];                  // the Gauss-Newton row of a feature: matA(i, 0..5), matB(i), selected (1 / 0)
     __shared__ long long spi[QPB / 16][56];         // exact fixed-point images (coarse, fine) of the sums of 16 consecutive features
     __shared__ double ssum[28], stmp[56];
-    __shared__ float spt[5][3][QPB];                // the five neighbours' coordinates, in the record's order
     __shared__ float sd4[QPB];                      // squared distance of the fifth nearest (the callers' gate)
     __shared__ int si[5][QPB];                      // their map indices
-    __shared__ int sidr[5][QPB];                    // the record's indices (phase A compares its result with them)
     __shared__ float sori[4][QPB];
     __shared__ unsigned short sperm[QPB];           // position in the record of the j-th nearest (3 bits each)
     __shared__ unsigned char sfok[QPB], srefit[QPB];
@@ -1295,8 +1293,6 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
             sd4[ql] = INFINITY;
             srefit[ql] = 0;
         }
-#pragma unroll
-        for (int j = 0; j < 5; j++) { spt[j][0][ql] = pp[j].x; spt[j][1][ql] = pp[j].y; spt[j][2][ql] = pp[j].z; sidr[j][ql] = id[j]; }
         sori[0][ql] = ori.x; sori[1][ql] = ori.y; sori[2][ql] = ori.z; sori[3][ql] = ori.intensity;
         sperm[ql] = (unsigned short)perm; sfok[ql] = (unsigned char)fok;
         // the searching features, listed in feature order: rank inside the wavefront now, the wavefronts' offsets after the barrier
@@ -1346,15 +1342,24 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
                 const bool five = r.d[4] < 1.0f;
                 // the same five in the same order as the record (a search usually confirms them): its coordinates and its fit stand
                 bool same = five && use_prev && sfok[qs] != 0;
+                if (same) {                                    // (the record's indices: phase 0 of this workgroup just read them, an L1 hit)
+                    int idr[5];
 #pragma unroll
-                for (int j = 0; j < 5; j++) same = same && r.i[j] == sidr[j][qs];
-                if (!same) {
+                    for (int j = 0; j < 5; j++) idr[j] = a.nn_prev[(size_t)j * cap + ts];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) same = same && r.i[j] == idr[j];
+                }
+                if (!same && a.nn_prev) {
+                    // the new neighbours become the feature's record right here (phase B reads their coordinates back after the barrier)
                     const lvi_pt* __restrict__ map = a.mapds[w];
                     lvi_pt nbp[5];
 #pragma unroll
                     for (int j = 0; j < 5; j++) nbp[j] = map[five ? r.i[j] : 0];           // unconditional: the five loads travel together
 #pragma unroll
-                    for (int j = 0; j < 5; j++) { spt[j][0][qs] = nbp[j].x; spt[j][1][qs] = nbp[j].y; spt[j][2][qs] = nbp[j].z; }
+                    for (int j = 0; j < 5; j++) {
+                        a.nn_prev[(size_t)j * cap + ts] = five ? r.i[j] : -1;
+                        a.nn_pt[(size_t)j * cap + ts] = make_float4(nbp[j].x, nbp[j].y, nbp[j].z, 0.f);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 5; j++) si[j][qs] = r.i[j];
@@ -1381,19 +1386,30 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
             const unsigned perm = sperm[ql];
             fok = sfok[ql];
             if (refit) {
+                // the five, in (distance, index) order: from the feature's record (a searching feature's was rewritten by phase A;
+                // a feature whose order changed under the new pose reads its record through the permutation), or — without
+                // records (LVI_KNN_NO_BOUND) — from the map
                 lvi_pt nb[5];
+                const lvi_pt* __restrict__ map = a.mapds[isC ? 0 : 1];
 #pragma unroll
-                for (int j = 0; j < 5; j++) { const int m = (perm >> (3 * j)) & 7u; nb[j].x = spt[m][0][ql]; nb[j].y = spt[m][1][ql]; nb[j].z = spt[m][2][ql]; nb[j].intensity = 0.f; }
+                for (int j = 0; j < 5; j++) {
+                    const int m = (perm >> (3 * j)) & 7u;
+                    if (a.nn_prev) { const float4 v = a.nn_pt[(size_t)m * cap + t]; nb[j].x = v.x; nb[j].y = v.y; nb[j].z = v.z; }
+                    else { const lvi_pt v = map[five ? si[j][ql] : 0]; nb[j].x = v.x; nb[j].y = v.y; nb[j].z = v.z; }
+                    nb[j].intensity = 0.f;
+                }
                 if (five) {
                     bool valid;
                     if (isC) valid = corner_fit(nb, f1, f2); else valid = surf_fit(nb, f1);
                     fok = valid ? 1u : 2u;
                 } else fok = 0u;
-                if (a.nn_prev) {                            // the record follows the fit: neighbours in the fit's order, their coordinates, the fit
+                if (a.nn_prev) {
+                    if (perm != PERM_ID) {                  // the record follows the fit: neighbours in the fit's order, with their coordinates
 #pragma unroll
-                    for (int j = 0; j < 5; j++) {
-                        a.nn_prev[(size_t)j * cap + t] = five ? si[j][ql] : -1;
-                        a.nn_pt[(size_t)j * cap + t] = make_float4(nb[j].x, nb[j].y, nb[j].z, 0.f);
+                        for (int j = 0; j < 5; j++) {
+                            a.nn_prev[(size_t)j * cap + t] = si[j][ql];
+                            a.nn_pt[(size_t)j * cap + t] = make_float4(nb[j].x, nb[j].y, nb[j].z, 0.f);
+                        }
                     }
                     a.fit[t] = f1; a.fit_ok[t] = (unsigned char)fok;
                     if (isC) a.fit2[t] = f2;

@@ -973,8 +973,9 @@ void lidar_allocate(LidarDev& d)
     { const char* e = getenv("LVI_KNN_NO_SKIP"); d.knn_skip = !(e && e[0] == '1'); }
     { const char* e = getenv("LVI_KNN_SLACK"); if (e) d.knn_slack = std::max(0.f, (float)atof(e)); }
     { const char* e = getenv("LVI_VB_BINS"); if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && b <= VB_NB) { d.voxMap.bin_pts = a; d.voxMap.bin_max = b; } } }
-    if (d.P.batch_scans > 1) { d.icp_g1 = 2; d.icp_wide_from = 1; }      // (256 features per workgroup from iteration 1 on: 8 040 vs 7 930 scans/s; a single scan: 640 vs 612 us)
-    // (2 lanes per feature in throughput mode: 16 scans in flight 5 315 scans/s with 2 lanes, 5 140 with 4; one scan alone: 25 vs 20 us per iteration)
+    if (d.P.batch_scans > 1) { d.icp_g1 = 4; d.icp_wide_from = 1; }      // (256 features per workgroup from iteration 1 on: 8 040 vs 7 930 scans/s; a single scan: 640 vs 612 us)
+    // (lanes per feature after iteration 0: round 2's kernel preferred 2 in throughput mode; with the records in global memory both forms
+    //  run four wavefronts per SIMD and 4 lanes win: 7 177 vs 7 090 scans/s)
     { const char* e = getenv("LVI_ICP_G0"); if (e) d.icp_g0 = atoi(e); }
     { const char* e = getenv("LVI_KNN_TILES"); d.knn_tiles = e && e[0] == '1'; }
     { const char* e = getenv("LVI_ICP_STAMP_ITER"); if (e) d.icp_stamp_iter = atoi(e); }
