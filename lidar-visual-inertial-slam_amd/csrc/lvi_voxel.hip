@@ -44,6 +44,7 @@ struct VoxArgs {
     int* planMiss;                                     // [nseg] vb_plan: a point outside the previous run's grid
     int plan_spec;                                     // this run takes bbox and per-bin counts in one pass (vb_plan); vox_setup validates the counts
     unsigned* wprefix;                                 // [nseg][VB_WG][VB_NB] points of bin b in the ranges of workgroups < w (deterministic partition)
+    int ch;                                            // points per accumulate chunk of this launch sequence: VB_CH, or a multiple of it when many slots fill the chip anyway (<= 32768: chunk-table counts are 16 bits)
 };
 
 __device__ __forceinline__ int seg_len(const VoxArgs& a, int s)
@@ -370,6 +371,34 @@ __device__ __forceinline__ unsigned long long fx_xyz(float v, int cell, double l
     return (unsigned long long)d2ll_rn_small(ldexp((double)v - (double)cell * leaf, k));        // |.| < 2^38 (vox_fx_setup); two's complement: sums wrap correctly
 }
 __device__ __forceinline__ unsigned long long fx_int(float v, int k) { return (unsigned long long)d2ll_rn_small(ldexp((double)v, k)); }
+// The same two images for the accumulate loops, from values held in registers: the grid record lives in global memory and the
+// compiler re-reads leaf_d / fx_k behind every LDS atomic (one L2 round trip per POINT in the ISA of round 2's loop).  The scale is a
+// power of two, so r * 2^k is exact and fma(r, 2^k, M) rounds exactly once, like ldexp(r, k) + M: the same integer; cellf is the
+// float floor itself (integer-valued, |.| < 2^31: the same double as the int conversion gives).
+struct VoxFx { float inv, mb0, mb1, mb2; unsigned mul1, mul2; double leaf, sc, sci; };
+__device__ __forceinline__ VoxFx vox_fx_of(const VoxGrid& g)
+{
+    VoxFx f;
+    f.inv = g.inv; f.mb0 = (float)g.min_b[0]; f.mb1 = (float)g.min_b[1]; f.mb2 = (float)g.min_b[2]; f.mul1 = g.mul1; f.mul2 = g.mul2;
+    f.leaf = g.leaf_d; f.sc = ldexp(1.0, g.fx_k); f.sci = ldexp(1.0, g.fx_ki);
+    return f;
+}
+__device__ __forceinline__ unsigned long long fx_rn_scaled(double r, double sc)
+{
+    const double M = 6755399441055744.0;
+    return (unsigned long long)(__double_as_longlong(fma(r, sc, M)) - __double_as_longlong(M));
+}
+// voxel idx (as vox_key_of_pt) and the four fixed-point terms of one point
+__device__ __forceinline__ unsigned vox_fx_point(const VoxFx& f, const lvi_pt& p, unsigned long long v[4])
+{
+    const float c0 = floorf(mul_rn(p.x, f.inv)), c1 = floorf(mul_rn(p.y, f.inv)), c2 = floorf(mul_rn(p.z, f.inv));
+    const int ijk0 = (int)sub_rn(c0, f.mb0), ijk1 = (int)sub_rn(c1, f.mb1), ijk2 = (int)sub_rn(c2, f.mb2);
+    v[0] = fx_rn_scaled((double)p.x - (double)c0 * f.leaf, f.sc);
+    v[1] = fx_rn_scaled((double)p.y - (double)c1 * f.leaf, f.sc);
+    v[2] = fx_rn_scaled((double)p.z - (double)c2 * f.leaf, f.sc);
+    v[3] = fx_rn_scaled((double)p.intensity, f.sci);
+    return (unsigned)ijk0 + (unsigned)ijk1 * f.mul1 + (unsigned)ijk2 * f.mul2;
+}
 __device__ __forceinline__ float fx_mean_xyz(unsigned long long sum, unsigned cnt, int cell, double leaf, int k)
 {
     return (float)((double)cell * leaf + ldexp(__ll2double_rn((long long)sum) / (double)cnt, -k));
@@ -739,7 +768,7 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
     int v[PER], sum = 0, csum = 0, msum = 0, lsum = 0;
     const bool wide = a.grid[s].bin_shift > VB_CL_LOG;
     // chunks of a bin: none for a light bin (<= VB_LIGHT points: one wavefront of vb_light_kernel takes it), else ceil(n / VB_CH)
-    auto chunks_of = [&](int n) { return wide ? (n > 0 ? 1 : 0) : (n <= VB_LIGHT ? 0 : (n + VB_CH - 1) / VB_CH); };
+    auto chunks_of = [&](int n) { return wide ? (n > 0 ? 1 : 0) : (n <= VB_LIGHT ? 0 : (n + a.ch - 1) / a.ch); };
 #pragma unroll
     for (int j = 0; j < PER; j++) v[j] = (int)cnt_src[(size_t)min((int)threadIdx.x * PER + j, VB_NB - 1) * cnt_stride];   // all 16 loads in flight
 #pragma unroll
@@ -842,19 +871,21 @@ template <int NT = 256>
 __device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, const lvi_pt* __restrict__ pts, int q0, int q1, unsigned k0, int cells)
 {
     constexpr int NL = 8;                               // loads in flight per lane
+    const VoxFx f = vox_fx_of(g);
     for (int i0 = q0 + threadIdx.x; i0 < q1; i0 += NL * NT) {
         lvi_pt p[NL]; bool ok[NL];
 #pragma unroll
-        for (int u = 0; u < NL; u++) { ok[u] = i0 + u * NT < q1; if (ok[u]) p[u] = pts[i0 + u * NT]; }
+        for (int u = 0; u < NL; u++) { const int i = i0 + u * NT; ok[u] = i < q1; p[u] = pts[min(i, q1 - 1)]; }    // unconditional loads, lanes masked below
 #pragma unroll
         for (int u = 0; u < NL; u++) {
-            if (!ok[u]) continue;
-            const unsigned c = vox_key_of_pt(g, p[u]) - k0;
-            if (c >= (unsigned)cells) continue;                         // another sub-range of a wide bin
-            int cell[3];
-            vox_cell_abs(g, p[u], cell);
-            atomicAdd(&L.sx[c], fx_xyz(p[u].x, cell[0], g.leaf_d, g.fx_k)); atomicAdd(&L.sy[c], fx_xyz(p[u].y, cell[1], g.leaf_d, g.fx_k));
-            atomicAdd(&L.sz[c], fx_xyz(p[u].z, cell[2], g.leaf_d, g.fx_k)); atomicAdd(&L.si[c], fx_int(p[u].intensity, g.fx_ki));
+            unsigned long long v[4];
+            const unsigned c = vox_fx_point(f, p[u], v) - k0;
+            if (!ok[u] || c >= (unsigned)cells) continue;               // (c: another sub-range of a wide bin)
+#ifdef VB_EXP_HALF
+            atomicAdd(&L.sx[c], v[0] ^ v[1]); atomicAdd(&L.sz[c], v[2] ^ v[3]);
+#else
+            atomicAdd(&L.sx[c], v[0]); atomicAdd(&L.sy[c], v[1]); atomicAdd(&L.sz[c], v[2]); atomicAdd(&L.si[c], v[3]);
+#endif
             atomicAdd(&L.cn[c], 1u);
         }
     }
@@ -915,19 +946,20 @@ __device__ __forceinline__ void vb_light_items(const VoxArgs& a, int s, const Vo
     lvi_pt* __restrict__ stg = a.staging + (size_t)s * a.seg_cap;
     uint2* __restrict__ skc = a.stagingKC + (size_t)s * a.seg_cap;
     constexpr int PP = VB_LIGHT / 64;                   // points per lane
+    const VoxFx f = vox_fx_of(g);
     for (int item = blockIdx.x * 4 + wv; item < nl; item += gridDim.x * 4) {
         const int b = lb[item];
         const int p0 = bs[b], p1 = bs[b + 1];
         const unsigned kbase = (unsigned)b << sh;
         if (ln < 16) L.bm[ln] = 0ull;
         wave_lds_sync();
-        lvi_pt p[PP]; unsigned c[PP]; bool ok[PP];
+        lvi_pt p[PP]; unsigned c[PP]; bool ok[PP]; unsigned long long v[PP][4];
 #pragma unroll
-        for (int u = 0; u < PP; u++) { const int i = p0 + ln + 64 * u; ok[u] = i < p1; if (ok[u]) p[u] = pts[i]; }
+        for (int u = 0; u < PP; u++) { const int i = p0 + ln + 64 * u; ok[u] = i < p1; p[u] = pts[min(i, p1 - 1)]; }      // p0 < p1 for a listed bin
 #pragma unroll
         for (int u = 0; u < PP; u++) {
-            c[u] = 0u;
-            if (ok[u]) { c[u] = (vox_key_of_pt(g, p[u]) - kbase) & (unsigned)(VB_TAB - 1); atomicOr(&L.bm[c[u] >> 6], 1ull << (c[u] & 63u)); }
+            c[u] = (vox_fx_point(f, p[u], v[u]) - kbase) & (unsigned)(VB_TAB - 1);
+            if (ok[u]) atomicOr(&L.bm[c[u] >> 6], 1ull << (c[u] & 63u));
         }
         wave_lds_sync();
         const int pc = ln < 16 ? __popcll(L.bm[ln]) : 0;
@@ -941,10 +973,7 @@ __device__ __forceinline__ void vb_light_items(const VoxArgs& a, int s, const Vo
             if (!ok[u]) continue;
             const unsigned w = c[u] >> 6;
             const int slot = (int)L.base[w] + __popcll(L.bm[w] & ((1ull << (c[u] & 63u)) - 1ull));
-            int cell[3];
-            vox_cell_abs(g, p[u], cell);
-            atomicAdd(&L.sx[slot], fx_xyz(p[u].x, cell[0], g.leaf_d, g.fx_k)); atomicAdd(&L.sy[slot], fx_xyz(p[u].y, cell[1], g.leaf_d, g.fx_k));
-            atomicAdd(&L.sz[slot], fx_xyz(p[u].z, cell[2], g.leaf_d, g.fx_k)); atomicAdd(&L.si[slot], fx_int(p[u].intensity, g.fx_ki));
+            atomicAdd(&L.sx[slot], v[u][0]); atomicAdd(&L.sy[slot], v[u][1]); atomicAdd(&L.sz[slot], v[u][2]); atomicAdd(&L.si[slot], v[u][3]);
             atomicAdd(&L.cn[slot], 1u);
             L.cell[slot] = (unsigned short)c[u];        // every point of the cell writes the same value
         }
@@ -963,7 +992,7 @@ __device__ __forceinline__ void vb_light_items(const VoxArgs& a, int s, const Vo
 // the chunks of a larger bin leave their LDS tables in chunkTab and vb_merge adds them up (no global atomics,
 // so a bin with 10^5 points is spread over 25 workgroups instead of keeping one busy for 0.2 ms).
 template <int NT>
-__global__ __launch_bounds__(NT) void vb_accum_kernel(Batch<VoxArgs> B_)
+__global__ __launch_bounds__(NT, 4) void vb_accum_kernel(Batch<VoxArgs> B_)
 {
     const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
@@ -1010,7 +1039,7 @@ __global__ __launch_bounds__(NT) void vb_accum_kernel(Batch<VoxArgs> B_)
             if (tid == 0) a.binVox[(size_t)s * VB_NB + b] = carry;
             continue;
         }
-        const int q0 = p0 + j * VB_CH, q1 = min(p1, q0 + VB_CH);
+        const int q0 = p0 + j * a.ch, q1 = min(p1, q0 + a.ch);
         vb_zero<NT>(L, cells);
         vb_add_points<NT>(L, g, pts, q0, q1, kbase, cells);
         if (nch == 1) {
@@ -1032,7 +1061,7 @@ __global__ __launch_bounds__(NT) void vb_accum_kernel(Batch<VoxArgs> B_)
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 const int c = tid * PER + q;
-                const unsigned m = c < cells ? L.cn[c] : 0u;                 // m <= VB_CH < 2^16, c < 2^10
+                const unsigned m = c < cells ? L.cn[c] : 0u;                 // m <= a.ch < 2^16, c < 2^10
                 if (m) { tv[r] = L.sx[c]; tv[VB_TAB + r] = L.sy[c]; tv[2 * VB_TAB + r] = L.sz[c]; tv[3 * VB_TAB + r] = L.si[c]; tc[r] = ((unsigned)c << 16) | m; r++; }
             }
             if (tid == 0) tc[VB_TAB] = (unsigned)tot;
@@ -1190,7 +1219,7 @@ static VoxArgs make_args(const VoxelPlan& p)
                    p.d_binCount, p.d_binStart, p.d_cursor, p.d_binVox, p.d_binOut, p.d_bucketed, p.d_staging, p.d_stagingKC, p.h_ncells,
                    p.d_chunkStart, p.d_multiStart, p.d_chunkBin, p.max_chunks, p.d_lightBin, p.d_multiOwner, p.d_chunkTabV, p.d_chunkTabC, p.max_multi,
                    {p.n_host[0], p.n_host[1], p.n_host[2], p.n_host[3]}, (p.use_n_host && p.nseg <= 4) ? 1 : 0,
-                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max, ((p.plan_per_run && p.d_wprefix) || (p.bbox_cached && p.hist_cached)) ? p.d_binCountCached : nullptr, p.d_binCountCached, p.d_planMiss, (p.plan_per_run && p.d_wprefix) ? 1 : 0, p.d_wprefix};
+                   {p.n_dev[0], p.n_dev[1], p.n_dev[2], p.n_dev[3]}, p.bin_pts, p.bin_max, ((p.plan_per_run && p.d_wprefix) || (p.bbox_cached && p.hist_cached)) ? p.d_binCountCached : nullptr, p.d_binCountCached, p.d_planMiss, (p.plan_per_run && p.d_wprefix) ? 1 : 0, p.d_wprefix, VB_CH};
 }
 
 void VoxelPlan::set_static(const Ctx& ctx, const VoxSegStatic* host_segs)
@@ -1526,7 +1555,9 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
         return;
     }
     Batch<VoxArgs> B;
-    for (int z = 0; z < S; z++) { B.a[z] = make_args(*plans[z]); plans[z]->last_mode = mode; }
+    static const int ch_env = getenv("LVI_VB_CH") ? atoi(getenv("LVI_VB_CH")) : 0;
+    const int ch = ch_env >= VB_CH && ch_env <= 32768 ? ch_env : VB_CH;
+    for (int z = 0; z < S; z++) { B.a[z] = make_args(*plans[z]); B.a[z].ch = ch; plans[z]->last_mode = mode; }
     for (int z = S; z < MAX_BATCH; z++) B.a[z] = B.a[0];
     const VoxArgs& a = B.a[0];
     char nm[16][48];
