@@ -109,6 +109,16 @@ inline dim3 zdim(dim3 g, int S) { g.z = (unsigned)S; return g; }
 // ---------------------------------------------------------------------------
 #define LVI_WAVE 64
 
+// a pointer read from a device-side record has no known address space: loads through it compile to flat_load (LDS-aperture test,
+// counted on lgkmcnt together with the LDS traffic).  The arrays of this library live in global memory: load as such.
+typedef float lvi_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lvi_pt ld_global_pt(const lvi_pt* p)
+{
+    const lvi_f4 v = *(const __attribute__((address_space(1))) lvi_f4*)p;
+    lvi_pt o; o.x = v.x; o.y = v.y; o.z = v.z; o.intensity = v.w;
+    return o;
+}
+__device__ __forceinline__ uint8_t ld_global_u8(const uint8_t* p) { return *(const __attribute__((address_space(1))) uint8_t*)p; }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }

@@ -241,6 +241,37 @@ __device__ __forceinline__ unsigned vox_key_of_pt(const VoxGrid& g, const lvi_pt
     const int ijk2 = (int)sub_rn(floorf(mul_rn(p.z, g.inv)), (float)g.min_b[2]);
     return (unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2;
 }
+// … from values held in registers: the grid record lives in global memory, and behind an LDS atomic or a store the compiler reads
+// inv / min_b / mul again — one L2 round trip per POINT in the ISA of the partition kernels of round 2
+struct VoxKeyK { float inv, mb0, mb1, mb2; unsigned mul1, mul2; };
+__device__ __forceinline__ VoxKeyK vox_keyk_of(const VoxGrid& g)
+{
+    VoxKeyK k;
+    k.inv = g.inv; k.mb0 = (float)g.min_b[0]; k.mb1 = (float)g.min_b[1]; k.mb2 = (float)g.min_b[2]; k.mul1 = g.mul1; k.mul2 = g.mul2;
+    return k;
+}
+__device__ __forceinline__ unsigned vox_key_k(const VoxKeyK& k, const lvi_pt& p)
+{
+    const int ijk0 = (int)sub_rn(floorf(mul_rn(p.x, k.inv)), k.mb0);
+    const int ijk1 = (int)sub_rn(floorf(mul_rn(p.y, k.inv)), k.mb1);
+    const int ijk2 = (int)sub_rn(floorf(mul_rn(p.z, k.inv)), k.mb2);
+    return (unsigned)ijk0 + (unsigned)ijk1 * k.mul1 + (unsigned)ijk2 * k.mul2;
+}
+// eight points of a lane: every load issued before the first use (clamped index, lanes masked afterwards; the mask bytes in a
+// second round under a uniform test)
+template <int NL, int STRIDE>
+__device__ __forceinline__ void vox_load_pts(const lvi_pt* __restrict__ in, const uint8_t* __restrict__ mask, int i_first, int i_end, lvi_pt p[NL], bool keep[NL])
+{
+#pragma unroll
+    for (int u = 0; u < NL; u++) { const int i = i_first + u * STRIDE; keep[u] = i < i_end; p[u] = ld_global_pt(in + max(min(i, i_end - 1), 0)); }
+    if (mask) {
+        uint8_t mk[NL];
+#pragma unroll
+        for (int u = 0; u < NL; u++) mk[u] = ld_global_u8(mask + max(min(i_first + u * STRIDE, i_end - 1), 0));
+#pragma unroll
+        for (int u = 0; u < NL; u++) keep[u] = keep[u] && mk[u] != 0;
+    }
+}
 __device__ __forceinline__ unsigned vox_key_of(const VoxGrid& g, const lvi_pt* in, const uint8_t* mask, int off, int i)
 {
     if (mask && !mask[off + i]) return g.sentinel;
@@ -507,17 +538,13 @@ __global__ __launch_bounds__(256) void vb_hist_kernel(Batch<VoxArgs> B_)
     const lvi_pt* __restrict__ in = a.st[s].in + off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
     // grid-stride over the tiles: one LDS histogram and one flush per workgroup, however many tiles it takes
+    const VoxKeyK kk = vox_keyk_of(g);
     for (int base = blockIdx.x * VB_TILE; base < n; base += gridDim.x * VB_TILE) {
         for (int u0 = 0; u0 < VB_TILE / 256; u0 += 8) {                  // eight unconditional loads in flight (clamped index, masked lanes)
             lvi_pt p[8]; bool keep[8];
+            vox_load_pts<8, 256>(in, mask, base + u0 * 256 + threadIdx.x, n, p, keep);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = base + (u0 + u) * 256 + threadIdx.x, ic = min(i, n - 1);
-                keep[u] = i < n && (!mask || mask[ic]);
-                p[u] = in[ic];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) if (keep[u]) atomicAdd(&cnt[vox_key_of_pt(g, p[u]) >> sh], 1u);
+            for (int u = 0; u < 8; u++) if (keep[u]) atomicAdd(&cnt[vox_key_k(kk, p[u]) >> sh], 1u);
         }
     }
     __syncthreads();
@@ -563,15 +590,11 @@ __global__ __launch_bounds__(256) void vb_plan_kernel(Batch<VoxArgs> B_)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     float imn = INFINITY, imx = -INFINITY;
     int c = 0, miss = 0;
+    const VoxKeyK kk = vox_keyk_of(g);
     for (int base = i0; base < i1; base += VB_STILE) {
         for (int u0 = 0; u0 < VB_STILE / 256; u0 += 8) {
             lvi_pt p[8]; bool keep[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = base + (u0 + u) * 256 + threadIdx.x, ic = max(min(i, i1 - 1), 0);
-                keep[u] = i < i1 && (!mask || mask[ic]);
-                p[u] = in[ic];
-            }
+            vox_load_pts<8, 256>(in, mask, base + u0 * 256 + threadIdx.x, i1, p, keep);
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 if (!keep[u]) continue;
@@ -580,11 +603,11 @@ __global__ __launch_bounds__(256) void vb_plan_kernel(Batch<VoxArgs> B_)
                 imn = fminf(imn, p[u].intensity); imx = fmaxf(imx, p[u].intensity);
                 c++;
                 if (spec) {
-                    const int ijk0 = (int)sub_rn(floorf(mul_rn(p[u].x, g.inv)), (float)g.min_b[0]);
-                    const int ijk1 = (int)sub_rn(floorf(mul_rn(p[u].y, g.inv)), (float)g.min_b[1]);
-                    const int ijk2 = (int)sub_rn(floorf(mul_rn(p[u].z, g.inv)), (float)g.min_b[2]);
+                    const int ijk0 = (int)sub_rn(floorf(mul_rn(p[u].x, kk.inv)), kk.mb0);
+                    const int ijk1 = (int)sub_rn(floorf(mul_rn(p[u].y, kk.inv)), kk.mb1);
+                    const int ijk2 = (int)sub_rn(floorf(mul_rn(p[u].z, kk.inv)), kk.mb2);
                     if ((unsigned)ijk0 < (unsigned)d0 && (unsigned)ijk1 < (unsigned)d1 && (unsigned)ijk2 < (unsigned)d2)
-                        atomicAdd(&cnt[((unsigned)ijk0 + (unsigned)ijk1 * g.mul1 + (unsigned)ijk2 * g.mul2) >> sh], 1u);
+                        atomicAdd(&cnt[((unsigned)ijk0 + (unsigned)ijk1 * kk.mul1 + (unsigned)ijk2 * kk.mul2) >> sh], 1u);
                     else miss = 1;
                 }
             }
@@ -642,17 +665,13 @@ __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
     const int off = a.dyn[s].in_off;
     const lvi_pt* __restrict__ in = a.st[s].in + off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
+    const VoxKeyK kk = vox_keyk_of(g);
     for (int base = i0; base < i1; base += VB_STILE) {
         for (int u0 = 0; u0 < VB_STILE / 256; u0 += 8) {
             lvi_pt p[8]; bool keep[8];
+            vox_load_pts<8, 256>(in, mask, base + u0 * 256 + threadIdx.x, i1, p, keep);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = base + (u0 + u) * 256 + threadIdx.x, ic = min(i, i1 - 1);
-                keep[u] = i < i1 && (!mask || mask[ic]);
-                p[u] = in[ic];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) if (keep[u]) atomicAdd(&cnt[vox_key_of_pt(g, p[u]) >> sh], 1u);
+            for (int u = 0; u < 8; u++) if (keep[u]) atomicAdd(&cnt[vox_key_k(kk, p[u]) >> sh], 1u);
         }
     }
     __syncthreads();
@@ -722,19 +741,14 @@ __global__ __launch_bounds__(256) void vb_scatter_det_kernel(Batch<VoxArgs> B_)
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
     lvi_pt* __restrict__ dst = a.bucketed + (size_t)s * a.seg_cap;
     constexpr int IT = VB_STILE / 256;
+    const VoxKeyK kk = vox_keyk_of(g);
     for (int base = i0; base < i1; base += VB_STILE) {
         lvi_pt p[IT]; int bin[IT]; unsigned rk[IT]; bool keep[IT];
+        // unconditional loads (index clamped into the range, the lane masked afterwards): behind a per-element branch every
+        // load of the tile waited for the one before it
+        vox_load_pts<IT, 256>(in, mask, base + threadIdx.x, i1, p, keep);
 #pragma unroll
-        for (int u = 0; u < IT; u++) {
-            // unconditional loads (index clamped into the range, the lane masked afterwards): behind a per-element branch every
-            // load of the tile waited for the one before it
-            const int i = base + u * 256 + threadIdx.x;
-            const int ic = min(i, i1 - 1);
-            keep[u] = i < i1 && (!mask || mask[ic]);
-            p[u] = in[ic];
-        }
-#pragma unroll
-        for (int u = 0; u < IT; u++) bin[u] = keep[u] ? (int)(vox_key_of_pt(g, p[u]) >> sh) : -1;
+        for (int u = 0; u < IT; u++) bin[u] = keep[u] ? (int)(vox_key_k(kk, p[u]) >> sh) : -1;
 #pragma unroll
         for (int u = 0; u < IT; u++) {
             const WaveRun r = wave_runs((unsigned)bin[u]);
@@ -819,15 +833,10 @@ __global__ __launch_bounds__(256) void vb_scatter_kernel(Batch<VoxArgs> B_)
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
     constexpr int IT = VB_STILE / 256;
     lvi_pt p[IT]; int bin[IT]; unsigned rk[IT]; bool keep[IT];
+    const VoxKeyK kk = vox_keyk_of(g);
+    vox_load_pts<IT, 256>(in, mask, base + threadIdx.x, n, p, keep);     // unconditional loads, clamped index (base < n here), lanes masked afterwards
 #pragma unroll
-    for (int u = 0; u < IT; u++) {                      // unconditional loads, clamped index (base < n here), lanes masked afterwards
-        const int i = base + u * 256 + threadIdx.x;
-        const int ic = min(i, n - 1);
-        keep[u] = i < n && (!mask || mask[ic]);
-        p[u] = in[ic];
-    }
-#pragma unroll
-    for (int u = 0; u < IT; u++) bin[u] = keep[u] ? (int)(vox_key_of_pt(g, p[u]) >> sh) : -1;
+    for (int u = 0; u < IT; u++) bin[u] = keep[u] ? (int)(vox_key_k(kk, p[u]) >> sh) : -1;
 #pragma unroll
     for (int u = 0; u < IT; u++) {                      // rank inside (tile, bin): any order will do; one LDS atomic per run of lanes,
         const WaveRun r = wave_runs((unsigned)bin[u]);  // so that a run lands on consecutive addresses (measured: 56 vs 59 us)
@@ -885,10 +894,10 @@ __device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, cons
             atomicAdd(&L.sx[c], v[0] ^ v[1]); atomicAdd(&L.sz[c], v[2] ^ v[3]);
 #else
             atomicAdd(&L.sx[c], v[0]); atomicAdd(&L.sy[c], v[1]); atomicAdd(&L.sz[c], v[2]); atomicAdd(&L.si[c], v[3]);
-#endif
             atomicAdd(&L.cn[c], 1u);
         }
     }
+#endif
     __syncthreads();
 }
 
@@ -992,7 +1001,7 @@ __device__ __forceinline__ void vb_light_items(const VoxArgs& a, int s, const Vo
 // the chunks of a larger bin leave their LDS tables in chunkTab and vb_merge adds them up (no global atomics,
 // so a bin with 10^5 points is spread over 25 workgroups instead of keeping one busy for 0.2 ms).
 template <int NT>
-__global__ __launch_bounds__(NT, 4) void vb_accum_kernel(Batch<VoxArgs> B_)
+__global__ __launch_bounds__(NT) void vb_accum_kernel(Batch<VoxArgs> B_)
 {
     const VoxArgs& a = B_.a[blockIdx.z];
     const int s = blockIdx.y;
