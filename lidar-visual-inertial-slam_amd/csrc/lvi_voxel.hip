@@ -890,14 +890,10 @@ __device__ __forceinline__ void vb_add_points(VbCells& L, const VoxGrid& g, cons
             unsigned long long v[4];
             const unsigned c = vox_fx_point(f, p[u], v) - k0;
             if (!ok[u] || c >= (unsigned)cells) continue;               // (c: another sub-range of a wide bin)
-#ifdef VB_EXP_HALF
-            atomicAdd(&L.sx[c], v[0] ^ v[1]); atomicAdd(&L.sz[c], v[2] ^ v[3]);
-#else
             atomicAdd(&L.sx[c], v[0]); atomicAdd(&L.sy[c], v[1]); atomicAdd(&L.sz[c], v[2]); atomicAdd(&L.si[c], v[3]);
             atomicAdd(&L.cn[c], 1u);
         }
     }
-#endif
     __syncthreads();
 }
 
