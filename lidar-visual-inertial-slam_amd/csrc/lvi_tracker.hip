@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void pyrdown_kernel(const uint8_t* __restrict_
 struct LkArgs {
     Pyr prev, next;
     const float* prev_xy; float* next_xy; uint8_t* status; float* err;
+    float* h_next_xy; uint8_t* h_status; float* h_err;     // host-mapped mirrors of the three results (nullptr: none): get_lk reads them after one wait, no copy commands
     int n, win, max_level, max_count;
     double epsilon; float min_eig;
 };
@@ -77,38 +78,69 @@ struct ClaheArgs {
     int W, H, tilesX, tilesY, tw, th, clipLimit; float lutScale;
 };
 
-__global__ __launch_bounds__(256) void clahe_lut_kernel(ClaheArgs a)
+__global__ __launch_bounds__(1024) void clahe_lut_kernel(ClaheArgs a)
 {
-    __shared__ int hist[256];
-    __shared__ int ws[8];
-    const int k = blockIdx.x, tx = k % a.tilesX, ty = k / a.tilesX, tid = threadIdx.x;
-    hist[tid] = 0;
+    // 1024 threads per tile, four pixels per load, one histogram per wavefront (a tile of the 1280 x 720 frame is 14 400 pixels: 256
+    // threads reading bytes one by one into ONE histogram were 32 us of the node's frame — 64 workgroups, 56 dependent rounds each)
+    __shared__ int whist[16][256];
+    __shared__ int ws[17];
+    const int k = blockIdx.x, tx = k % a.tilesX, ty = k / a.tilesX, tid = threadIdx.x, wv = tid >> 6;
+    for (int i = tid; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
     __syncthreads();
     const int area = a.tw * a.th;
-    for (int idx = tid; idx < area; idx += 256) {
-        const int x = tx * a.tw + idx % a.tw, y = ty * a.th + idx / a.tw;
-        // right / bottom extension of images that are not a multiple of the tile grid: BORDER_REFLECT_101
-        const int sx = x < a.W ? x : reflect101(x, a.W), sy = y < a.H ? y : reflect101(y, a.H);
-        atomicAdd(&hist[a.src[(size_t)sy * a.W + sx]], 1);
+    const int x0 = tx * a.tw, y0 = ty * a.th;
+    const bool vec = (a.tw & 3) == 0 && (a.W & 3) == 0 && x0 + a.tw <= a.W && y0 + a.th <= a.H;     // (x0 is then a multiple of 4 as well)
+    if (vec) {
+        const int qw = a.tw >> 2, nq = qw * a.th;
+        constexpr int NL = 4;
+        for (int q0 = tid; q0 < nq; q0 += NL * 1024) {
+            unsigned v[NL];
+#pragma unroll
+            for (int u = 0; u < NL; u++) {
+                const int q = min(q0 + u * 1024, nq - 1);
+                v[u] = *reinterpret_cast<const unsigned*>(a.src + (size_t)(y0 + q / qw) * a.W + x0 + 4 * (q % qw));
+            }
+#pragma unroll
+            for (int u = 0; u < NL; u++) {
+                if (q0 + u * 1024 >= nq) continue;
+                atomicAdd(&whist[wv][v[u] & 255u], 1); atomicAdd(&whist[wv][(v[u] >> 8) & 255u], 1);
+                atomicAdd(&whist[wv][(v[u] >> 16) & 255u], 1); atomicAdd(&whist[wv][v[u] >> 24], 1);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < area; idx += 1024) {
+            const int x = x0 + idx % a.tw, y = y0 + idx / a.tw;
+            // right / bottom extension of images that are not a multiple of the tile grid: BORDER_REFLECT_101
+            const int sx = x < a.W ? x : reflect101(x, a.W), sy = y < a.H ? y : reflect101(y, a.H);
+            atomicAdd(&whist[wv][a.src[(size_t)sy * a.W + sx]], 1);
+        }
     }
     __syncthreads();
-    int hv = hist[tid];
+    // bins live in the first 256 threads; the others contribute zeros to the two scans (every thread reaches every barrier)
+    int hv = 0;
+    if (tid < 256) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) hv += whist[q][tid];
+    }
     if (a.clipLimit > 0) {
         const int excess = max(hv - a.clipLimit, 0);
         hv = min(hv, a.clipLimit);
         int clipped;
-        (void)block_excl_scan<256>(excess, ws, &clipped);
+        (void)block_excl_scan<1024>(excess, ws, &clipped);
         const int redistBatch = clipped / 256;
         const int residual = clipped - redistBatch * 256;
-        hv += redistBatch;
-        if (residual != 0) {
-            const int step = max(256 / residual, 1);
-            if (tid % step == 0 && tid / step < residual) hv++;
+        if (tid < 256) {
+            hv += redistBatch;
+            if (residual != 0) {
+                const int step = max(256 / residual, 1);
+                if (tid % step == 0 && tid / step < residual) hv++;
+            }
         }
     }
     int tot;
-    const int sum = block_excl_scan<256>(hv, ws, &tot) + hv;
+    const int sum = block_excl_scan<1024>(hv, ws, &tot) + hv;
     const int v = cv_round((float)sum * a.lutScale);
+    if (tid >= 256) return;
     a.lut[(size_t)k * 256 + tid] = (uint8_t)min(max(v, 0), 255);
 }
 
@@ -206,15 +238,21 @@ __global__ __launch_bounds__(64) void mask_circles_kernel(CircleArgs a)
 
 // undistortedPoints over [the kept points (host) ; the corners goodFeaturesToTrack just found (device)]: cur_pts of the next frame
 __global__ __launch_bounds__(64) void frame_concat_kernel(const float* __restrict__ kept, int n_kept, const float* __restrict__ found, const int* __restrict__ n_found,
-                                                          int cap, float* __restrict__ all_xy, int* __restrict__ n_all)
+                                                          const int* __restrict__ n_cand, int with_gftt, int cap, float* __restrict__ all_xy, int* __restrict__ d_hdr,
+                                                          int* __restrict__ h_hdr, float* __restrict__ h_new)
 {
-    const int nf = min(max(*n_found, 0), cap);
+    // kept: the caller's points in pinned host memory (read in place); h_hdr / h_new: the frame's result block in pinned host memory —
+    // {n_new (or the pick kernel's negative code), n_cand, n_all}, then the new corners: the frame end is kernels and one wait
+    const int nraw = with_gftt ? *n_found : 0;
+    const int nf = min(max(nraw, 0), cap);
     const int n = min(n_kept + nf, cap);
     for (int i = threadIdx.x; i < n; i += 64) {
         const float* src = i < n_kept ? kept + 2 * i : found + 2 * (i - n_kept);
-        all_xy[2 * i] = src[0]; all_xy[2 * i + 1] = src[1];
+        const float x = src[0], y = src[1];
+        all_xy[2 * i] = x; all_xy[2 * i + 1] = y;
+        if (i >= n_kept) { h_new[2 * (i - n_kept)] = x; h_new[2 * (i - n_kept) + 1] = y; }
     }
-    if (threadIdx.x == 0) *n_all = n;
+    if (threadIdx.x == 0) { d_hdr[2] = n; h_hdr[0] = nraw; h_hdr[1] = with_gftt ? *n_cand : 0; h_hdr[2] = n; }
 }
 __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
 {
@@ -413,6 +451,7 @@ __global__ __launch_bounds__(64) void lk_kernel(LkArgs a)
     if (l == 0) {
         a.next_xy[2 * f] = outx; a.next_xy[2 * f + 1] = outy;
         a.status[f] = st ? 1 : 0; a.err[f] = errv;
+        if (a.h_next_xy) { a.h_next_xy[2 * f] = outx; a.h_next_xy[2 * f + 1] = outy; a.h_status[f] = st ? 1 : 0; a.h_err[f] = errv; }
     }
 }
 
@@ -814,6 +853,11 @@ struct lvi_tracker {
     // frame in a process with many GPU mappings, and the call had to wait for it before returning
     uint8_t* h_frame[2] = {nullptr, nullptr}; hipEvent_t ev_frame[2] = {nullptr, nullptr}; int frame_slot = 0;
     float* h_pts[2] = {nullptr, nullptr}; hipEvent_t ev_pts[2] = {nullptr, nullptr}; int pts_slot = 0;      // the same for cur_pts
+    // Small inputs and results do not travel through copy commands (a 1 KB hipMemcpyAsync is a 4 us blit kernel on the stream, and the node
+    // path had eleven of them per frame): kernels read the caller's points / circle centres in place from the pinned slots above and
+    // write the LK results and the frame's result block into pinned host memory; the host waits once and reads.
+    const float* cur_src = nullptr; int cur_slot = -1;       // points of the next run_lk (a pinned slot; its event is recorded behind the kernel that reads it)
+    float* h_lk = nullptr;                                   // [2 F] forw_xy, [F] err, [F bytes] status
 };
 
 namespace {
@@ -873,7 +917,7 @@ void run_clahe(lvi_tracker& t, const uint8_t* src, uint8_t* dst, int w, int h, d
     a.lutScale = static_cast<float>(255) / area;
     a.clipLimit = 0;
     if (clip > 0.0) a.clipLimit = std::max(static_cast<int>(clip * area / 256), 1);
-    LVI_LAUNCH(t.ctx, "clahe_lut", (double)w * h, hipLaunchKernelGGL(clahe_lut_kernel, dim3(tilesX * tilesY), dim3(256), 0, t.ctx.stream, a));
+    LVI_LAUNCH(t.ctx, "clahe_lut", (double)w * h, hipLaunchKernelGGL(clahe_lut_kernel, dim3(tilesX * tilesY), dim3(1024), 0, t.ctx.stream, a));
     LVI_LAUNCH(t.ctx, "clahe_interp", 2.0 * w * h, hipLaunchKernelGGL(clahe_interp_kernel, dim3(div_up(w, 64), div_up(h, 4)), dim3(256), 0, t.ctx.stream, a));
 }
 
@@ -939,6 +983,7 @@ int32_t lvi_tracker_create(const lvi_tracker_params* p, int32_t device, lvi_trac
             LVI_HIP(hipEventRecord(t->ev_pts[s], t->ctx.stream));
         }
         LVI_HIP(hipHostMalloc((void**)&t->h_frame_out, sizeof(float) * (4 + 4 * (size_t)std::max(t->P.max_features, 64)), hipHostMallocDefault));
+        LVI_HIP(hipHostMalloc((void**)&t->h_lk, sizeof(float) * 4 * (size_t)std::max(t->P.max_features, 64), hipHostMallocDefault));
         LVI_HIP(hipStreamSynchronize(t->ctx.stream));
         return LVI_OK;
     });
@@ -963,6 +1008,7 @@ void lvi_tracker_destroy(lvi_tracker* t)
         if (t->ev_pts[s]) (void)hipEventDestroy(t->ev_pts[s]);
     }
     if (t->h_frame_out) (void)hipHostFree(t->h_frame_out);
+    if (t->h_lk) (void)hipHostFree(t->h_lk);
     if (t->ctx.stream) (void)hipStreamDestroy(t->ctx.stream);
     delete t;
 }
@@ -1046,8 +1092,7 @@ int32_t lvi_tracker_set_points(lvi_tracker* t, const float* cur_xy, int32_t n)
             const int slot = (t->pts_slot ^= 1);
             LVI_HIP(hipEventSynchronize(t->ev_pts[slot]));
             std::memcpy(t->h_pts[slot], cur_xy, sizeof(float) * 2 * (size_t)n);
-            LVI_HIP(hipMemcpyAsync(t->d_cur_xy, t->h_pts[slot], sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
-            LVI_HIP(hipEventRecord(t->ev_pts[slot], t->ctx.stream));
+            t->cur_src = t->h_pts[slot]; t->cur_slot = slot;               // lk_kernel reads them in place
         }
         t->n_pts = n; t->have_lk = false;
         return LVI_OK;
@@ -1060,7 +1105,9 @@ int32_t lvi_tracker_run_lk(lvi_tracker* t)
     return tguard(t, [&]() -> int32_t {
         LkArgs a{};
         a.prev = t->pyr[t->cur]; a.next = t->pyr[t->forw];
-        a.prev_xy = t->d_cur_xy; a.next_xy = t->d_forw_xy; a.status = t->d_status; a.err = t->d_err;
+        const size_t F = (size_t)std::max(t->P.max_features, 64);
+        a.prev_xy = t->cur_src ? t->cur_src : t->d_cur_xy; a.next_xy = t->d_forw_xy; a.status = t->d_status; a.err = t->d_err;
+        a.h_next_xy = t->h_lk; a.h_err = t->h_lk + 2 * F; a.h_status = reinterpret_cast<uint8_t*>(t->h_lk + 3 * F);
         a.n = t->n_pts; a.win = t->P.lk_win; a.max_level = std::min(a.prev.top, a.next.top);
         a.max_count = std::min(std::max(t->P.lk_max_iters, 0), 100);
         double eps = std::min(std::max(t->P.lk_eps, 0.), 10.);
@@ -1068,6 +1115,7 @@ int32_t lvi_tracker_run_lk(lvi_tracker* t)
         if (a.n > 0) {
             const double bytes = (double)a.n * (a.max_level + 1) * (24.0 * 24 + 22.0 * 22 * 4);
             LVI_LAUNCH(t->ctx, "lk_track", bytes, hipLaunchKernelGGL(lk_kernel, dim3(a.n), dim3(64), 0, t->ctx.stream, a));
+            if (t->cur_slot >= 0) LVI_HIP(hipEventRecord(t->ev_pts[t->cur_slot], t->ctx.stream));      // the slot is free again once this kernel has read it
         }
         t->have_lk = true;
         return LVI_OK;
@@ -1082,10 +1130,11 @@ int32_t lvi_tracker_get_lk(lvi_tracker* t, float* forw_xy, uint8_t* status, floa
     if (capacity < *n) return tfail(LVI_ERR_CAPACITY, "capacity too small");
     return tguard(t, [&]() -> int32_t {
         const int m = *n;
-        if (m && forw_xy) LVI_HIP(hipMemcpyAsync(forw_xy, t->d_forw_xy, sizeof(float) * 2 * m, hipMemcpyDeviceToHost, t->ctx.stream));
-        if (m && status) LVI_HIP(hipMemcpyAsync(status, t->d_status, (size_t)m, hipMemcpyDeviceToHost, t->ctx.stream));
-        if (m && err) LVI_HIP(hipMemcpyAsync(err, t->d_err, sizeof(float) * m, hipMemcpyDeviceToHost, t->ctx.stream));
-        LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+        const size_t F = (size_t)std::max(t->P.max_features, 64);
+        LVI_HIP(hipStreamSynchronize(t->ctx.stream));                      // lk_kernel wrote the results into pinned host memory
+        if (m && forw_xy) std::memcpy(forw_xy, t->h_lk, sizeof(float) * 2 * (size_t)m);
+        if (m && err) std::memcpy(err, t->h_lk + 2 * F, sizeof(float) * (size_t)m);
+        if (m && status) std::memcpy(status, t->h_lk + 3 * F, (size_t)m);
         return LVI_OK;
     });
 }
@@ -1159,15 +1208,18 @@ int32_t lvi_tracker_set_mask_circles(lvi_tracker* t, const float* centers_xy, in
     if (n > t->P.max_features) return tfail(LVI_ERR_CAPACITY, "too many circles");
     return tguard(t, [&]() -> int32_t {
         CircleArgs a{t->d_mask, t->w, t->h, t->d_centers, n, radius};
+        int slot = -1;
         if (n) {
-            const int slot = (t->centers_slot ^= 1);
+            slot = (t->centers_slot ^= 1);
             LVI_HIP(hipEventSynchronize(t->ev_centers[slot]));
             std::memcpy(t->h_centers[slot], centers_xy, sizeof(float) * 2 * (size_t)n);
-            LVI_HIP(hipMemcpyAsync(t->d_centers, t->h_centers[slot], sizeof(float) * 2 * n, hipMemcpyHostToDevice, t->ctx.stream));
-            LVI_HIP(hipEventRecord(t->ev_centers[slot], t->ctx.stream));
+            a.centers = t->h_centers[slot];                                 // read in place (pinned host memory)
         }
         LVI_LAUNCH(t->ctx, "mask_fill", (double)t->w * t->h, hipLaunchKernelGGL(mask_fill_kernel, dim3(div_up(div_up(t->w * t->h, 16), 256)), dim3(256), 0, t->ctx.stream, a));
-        if (n) LVI_LAUNCH(t->ctx, "mask_circles", 0, hipLaunchKernelGGL(mask_circles_kernel, dim3(n), dim3(64), 0, t->ctx.stream, a));
+        if (n) {
+            LVI_LAUNCH(t->ctx, "mask_circles", 0, hipLaunchKernelGGL(mask_circles_kernel, dim3(n), dim3(64), 0, t->ctx.stream, a));
+            LVI_HIP(hipEventRecord(t->ev_centers[slot], t->ctx.stream));
+        }
         t->have_mask = true;
         return LVI_OK;
     });
@@ -1192,24 +1244,22 @@ int32_t lvi_tracker_finish_frame(lvi_tracker* t, const lvi_mei_params* cam, cons
         const int F = t->P.max_features;
         for (int attempt = 0; attempt < 2; attempt++) {
             const bool with_gftt = t->gftt_pending;
+            const float* kept_src = t->d_un_in;
+            int slot = -1;
             if (n_kept) {
-                const int slot = (t->pts_slot ^= 1);
+                slot = (t->pts_slot ^= 1);
                 LVI_HIP(hipEventSynchronize(t->ev_pts[slot]));
                 std::memcpy(t->h_pts[slot], kept_xy, sizeof(float) * 2 * (size_t)n_kept);
-                LVI_HIP(hipMemcpyAsync(t->d_un_in, t->h_pts[slot], sizeof(float) * 2 * n_kept, hipMemcpyHostToDevice, t->ctx.stream));
-                LVI_HIP(hipEventRecord(t->ev_pts[slot], t->ctx.stream));
+                kept_src = t->h_pts[slot];                                  // read in place
             }
             int* d_hdr = reinterpret_cast<int*>(t->d_frame_out);
-            if (!with_gftt) LVI_HIP(hipMemsetAsync(t->d_out_n, 0, sizeof(int), t->ctx.stream));       // no new corners asked for
-            hipLaunchKernelGGL(frame_concat_kernel, dim3(1), dim3(64), 0, t->ctx.stream, t->d_un_in, n_kept, t->d_gftt_xy, t->d_out_n, F, t->d_all_xy, d_hdr + 2);
-            LVI_HIP(hipGetLastError());
+            int* h_hdr = reinterpret_cast<int*>(t->h_frame_out);
+            LVI_LAUNCH(t->ctx, "frame_concat", 0, hipLaunchKernelGGL(frame_concat_kernel, dim3(1), dim3(64), 0, t->ctx.stream, kept_src, n_kept, t->d_gftt_xy, t->d_out_n, t->d_ncand,
+                                                                     with_gftt ? 1 : 0, F, t->d_all_xy, d_hdr, h_hdr, t->h_frame_out + 4));
+            if (slot >= 0) LVI_HIP(hipEventRecord(t->ev_pts[slot], t->ctx.stream));
             if (cam) LVI_LAUNCH(t->ctx, "mei_undistort", 16.0 * F, hipLaunchKernelGGL(mei_undistort_kernel, dim3(div_up(F, 64)), dim3(64), 0, t->ctx.stream, *cam, t->d_all_xy, F,
-                                                                                       t->d_frame_out + 4 + 2 * (size_t)F, (const int*)(d_hdr + 2)));
-            LVI_HIP(hipMemcpyAsync(d_hdr, t->d_out_n, sizeof(int), hipMemcpyDeviceToDevice, t->ctx.stream));
-            LVI_HIP(hipMemcpyAsync(d_hdr + 1, t->d_ncand, sizeof(int), hipMemcpyDeviceToDevice, t->ctx.stream));
-            LVI_HIP(hipMemcpyAsync(t->d_frame_out + 4, t->d_gftt_xy, sizeof(float) * 2 * (size_t)F, hipMemcpyDeviceToDevice, t->ctx.stream));
-            LVI_HIP(hipMemcpyAsync(t->h_frame_out, t->d_frame_out, sizeof(float) * (4 + 4 * (size_t)F), hipMemcpyDeviceToHost, t->ctx.stream));   // the ONE read of the frame
-            LVI_HIP(hipStreamSynchronize(t->ctx.stream));
+                                                                                       t->h_frame_out + 4 + 2 * (size_t)F, (const int*)(d_hdr + 2)));
+            LVI_HIP(hipStreamSynchronize(t->ctx.stream));                   // the ONE wait of the frame end: both kernels wrote into pinned host memory
             const int* hdr = reinterpret_cast<const int*>(t->h_frame_out);
             if (with_gftt && hdr[0] == -2 && attempt == 0) { enqueue_gftt(t, t->gftt_pending_max, false); continue; }   // beyond the LDS form: redo in the radix form
             t->gftt_pending = false;
