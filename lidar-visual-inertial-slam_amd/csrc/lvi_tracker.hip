@@ -527,21 +527,22 @@ __global__ __launch_bounds__(256) void mineig_kernel(GfttArgs a)
     if (threadIdx.x == 0) a.maxPartial[blockIdx.y * gridDim.x + blockIdx.x] = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
 }
 
-__global__ __launch_bounds__(256) void gftt_thr_kernel(GfttArgs a, int npartial)
+// quality threshold = max over the (masked) min-eigenvalue image x qualityLevel (featureselect.cpp): the fold of mineig's per-workgroup
+// maxima.  Every workgroup of gftt_count folds the few thousand partial maxima itself (a separate one-workgroup launch was 4.6 us of
+// the node's frame); its first workgroup leaves the result for gftt_emit and the debug views.
+__device__ __forceinline__ float gftt_threshold(const GfttArgs& a, int npartial, unsigned* smax)
 {
     unsigned o = 0u;
     for (int i = threadIdx.x; i < npartial; i += 256) o = max(o, a.maxPartial[i]);
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) { const unsigned t = __shfl_xor(o, s, 64); o = t > o ? t : o; }
-    __shared__ unsigned smax[4];
     if (lane_id() == 0) smax[wave_id()] = o;
     __syncthreads();
-    if (threadIdx.x != 0) return;
     o = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-    *a.maxord = o;
     const double maxVal = o ? (double)ord2f(o) : 0.0;
-    *a.thr = (float)(maxVal * a.quality);
-    *a.total = 0;
+    const float thr = (float)(maxVal * a.quality);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *a.maxord = o; *a.thr = thr; }
+    return thr;
 }
 
 __device__ __forceinline__ bool gftt_is_cand(const GfttArgs& a, int x, int y, float thr)
@@ -566,9 +567,10 @@ __device__ __forceinline__ bool gftt_is_cand(const GfttArgs& a, int x, int y, fl
 }
 
 constexpr int CAND_TILE = 1024;
-__global__ __launch_bounds__(256) void gftt_count_kernel(GfttArgs a)
+__global__ __launch_bounds__(256) void gftt_count_kernel(GfttArgs a, int npartial)
 {
-    const float thr = *a.thr;
+    __shared__ unsigned smax[4];
+    const float thr = gftt_threshold(a, npartial, smax);
     const int base = blockIdx.x * CAND_TILE;
     int c = 0;
 #pragma unroll
@@ -578,30 +580,23 @@ __global__ __launch_bounds__(256) void gftt_count_kernel(GfttArgs a)
     block_excl_scan<256>(c, ws, &tot);
     if (threadIdx.x == 0) a.blockCnt[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(256) void gftt_scan_kernel(GfttArgs a, int nblk)
-{
-    __shared__ int ws[8];
-    int carry = 0;
-    for (int c = 0; c < nblk; c += 256) {
-        const int i = c + threadIdx.x;
-        const int v = (i < nblk) ? a.blockCnt[i] : 0;
-        int tot;
-        const int ex = block_excl_scan<256>(v, ws, &tot);
-        if (i < nblk) a.blockCnt[i] = carry + ex;
-        carry += tot;
-    }
-    if (threadIdx.x == 0) { *a.total = carry; a.d_n[0] = carry; a.d_nbits[0] = 32; }
-}
-__global__ __launch_bounds__(256) void gftt_emit_kernel(GfttArgs a)
+// ordered compaction; the prefix over the (<= a few thousand) per-tile counts is folded by every workgroup itself (the one-workgroup
+// scan launch in between was 4.8 us of the node's frame)
+__global__ __launch_bounds__(256) void gftt_emit_kernel(GfttArgs a, int nblk)
 {
     const float thr = *a.thr;
-    const int total = *a.total;
+    __shared__ int ws[8];
+    int bef = 0, all = 0;
+    for (int i = threadIdx.x; i < nblk; i += 256) { const int v = a.blockCnt[i]; all += v; bef += i < (int)blockIdx.x ? v : 0; }
+    int total, before;
+    (void)block_excl_scan<256>(all, ws, &total);
+    (void)block_excl_scan<256>(bef, ws, &before);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *a.total = total; a.d_n[0] = total; a.d_nbits[0] = 32; }
     const int base = blockIdx.x * CAND_TILE;
     bool h[4]; int c = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) { const int p = base + threadIdx.x * 4 + j; h[j] = (p < a.w * a.h) && gftt_is_cand(a, p % a.w, p / a.w, thr); c += h[j]; }
-    __shared__ int ws[8];
-    int r = a.blockCnt[blockIdx.x] + block_excl_scan<256>(c, ws, nullptr);
+    int r = before + block_excl_scan<256>(c, ws, nullptr);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (!h[j]) continue;
@@ -640,7 +635,7 @@ __global__ __launch_bounds__(SORTLDS ? 1024 : 64) void gftt_pick_kernel(PickArgs
     constexpr int ACC_MAX = SORTLDS ? 2048 : 4096, GRID_MAX = SORTLDS ? 4096 : 8192, CELL_CAP = 4;
     constexpr int NT = SORTLDS ? 1024 : 64;
     __shared__ short ax[ACC_MAX], ay[ACC_MAX], acx[ACC_MAX], acy[ACC_MAX];      // accepted corners and their grid cells (no division in the inner loop)
-    __shared__ unsigned char gcnt[GRID_MAX];
+    __shared__ unsigned gcnt[GRID_MAX];                                          // (words: the accepted corners of a batch enter their cells together, through atomics)
     __shared__ unsigned short gent[GRID_MAX * CELL_CAP];
     __shared__ unsigned long long band[SORTLDS ? GFTT_BAND : 1];
     __shared__ unsigned hist[SORTLDS ? 1024 : 1], hsub[SORTLDS ? 8 * 1024 : 1];      // hsub: eight copies (lane & 7) — weak candidates crowd the last bins
@@ -660,16 +655,26 @@ __global__ __launch_bounds__(SORTLDS ? 1024 : 64) void gftt_pick_kernel(PickArgs
     if (SORTLDS) for (int b = l; b < 8 * 1024; b += NT) hsub[b] = 0u;
     __syncthreads();
     int shift = 0;
+    constexpr int KPT = SORTLDS ? 16 : 1;
+    unsigned kreg[KPT];
     long long tq[6] = {0, 0, 0, 0, 0, 0}; int nbands = 0;
     if (SORTLDS && l == 0) tq[0] = clock64();
     if (SORTLDS) {
         // range of the value keys, then the histogram (keys ascend as values descend: bin 0 holds the strongest)
+        // (the first KPT keys of a thread stay in registers for all three passes — range, histogram, band placement; one round of
+        // loads, all in flight together: 14 k candidates were 14 dependent round trips per pass)
         unsigned kmn = 0xFFFFFFFFu, kmx = 0u;
-        for (int i = l; i < total; i += NT) { const unsigned k = a.keysA[i]; kmn = min(kmn, k); kmx = max(kmx, k); }
+#pragma unroll
+        for (int j = 0; j < KPT; j++) kreg[j] = a.keysA[min(l + j * NT, max(total - 1, 0))];
+#pragma unroll
+        for (int j = 0; j < KPT; j++) if (l + j * NT < total) { kmn = min(kmn, kreg[j]); kmx = max(kmx, kreg[j]); }
+        for (int i = l + KPT * NT; i < total; i += NT) { const unsigned k = a.keysA[i]; kmn = min(kmn, k); kmx = max(kmx, k); }
         atomicMin(&s_kmin, kmn); atomicMax(&s_kmax, kmx);
         __syncthreads();
         while (((s_kmax - s_kmin) >> shift) >= 1024u) shift++;
-        for (int i = l; i < total; i += NT) atomicAdd(&hsub[(l & 7) * 1024 + ((a.keysA[i] - s_kmin) >> shift)], 1u);
+#pragma unroll
+        for (int j = 0; j < KPT; j++) if (l + j * NT < total) atomicAdd(&hsub[(l & 7) * 1024 + ((kreg[j] - s_kmin) >> shift)], 1u);
+        for (int i = l + KPT * NT; i < total; i += NT) atomicAdd(&hsub[(l & 7) * 1024 + ((a.keysA[i] - s_kmin) >> shift)], 1u);
         __syncthreads();
         { unsigned v = 0u;
 #pragma unroll
@@ -712,13 +717,16 @@ __global__ __launch_bounds__(SORTLDS ? 1024 : 64) void gftt_pick_kernel(PickArgs
             // counting sort by bin (the bins ARE value order): a key goes to its bin's segment of the band, any place inside it …
             for (unsigned b = lo + (unsigned)l; b < hi; b += NT) hsub[b] = 0u;          // (hsub[0 .. 1024) serves as the bins' cursors now)
             __syncthreads();
-            for (int i = l; i < total; i += NT) {
-                const unsigned k = a.keysA[i], b = (k - s_kmin) >> shift;
+            auto place = [&](unsigned k, int i) {
+                const unsigned b = (k - s_kmin) >> shift;
                 if (b >= lo && b < hi) {
                     const unsigned seg = (b > 0 ? hist[b - 1] : 0u) - before;
                     band[seg + atomicAdd(&hsub[b], 1u)] = ((unsigned long long)k << 32) | (unsigned long long)(0xFFFFFFFFu - a.valsA[i]);
                 }
-            }
+            };
+#pragma unroll
+            for (int j = 0; j < KPT; j++) if (l + j * NT < total) place(kreg[j], l + j * NT);
+            for (int i = l + KPT * NT; i < total; i += NT) place(a.keysA[i], i);
             __syncthreads();
             count = (int)(hist[hi - 1] - before);
             {   // … and is then ranked among the few keys of its own bin (unique keys: the count of smaller ones is its place)
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(SORTLDS ? 1024 : 64) void gftt_pick_kernel(PickArgs
                             for (int dxc = -1; dxc <= 1 && alive; dxc++) {
                                 const int cx = xc + dxc;
                                 if (cx < 0 || cx >= gw) continue;
-                                const int c = cy * gw + cx, n = gcnt[c];
+                                const int c = cy * gw + cx, n = min((int)gcnt[c], CELL_CAP);
                                 for (int e = 0; e < n; e++) {
                                     const int k = gent[c * CELL_CAP + e];
                                     const float dx = (float)(x - ax[k]), dy = (float)(y - ay[k]);
@@ -773,32 +781,38 @@ __global__ __launch_bounds__(SORTLDS ? 1024 : 64) void gftt_pick_kernel(PickArgs
                         }
                     }
                 }
-                uint64_t m = __ballot(alive);
+                // accept rounds in registers: the strongest surviving lane is accepted, the lanes within min_dist of it drop out (a corner
+                // that close always lies in a neighbouring cell, so the plain distance test equals the grid's) — no LDS inside the loop
+                // (a table update per round was ~1 000 cycles: 68 us for 150 corners)
+                uint64_t m = __ballot(alive), accm = 0ull;
+                const int nacc0 = nacc;
                 while (m && nacc < limit) {
                     const int first = __ffsll((long long)m) - 1;
                     const int fx = __builtin_amdgcn_readlane(x, first), fy = __builtin_amdgcn_readlane(y, first);      // `first` is wave-uniform: scalar reads
-                    const int fxc = __builtin_amdgcn_readlane(xc, first), fyc = __builtin_amdgcn_readlane(yc, first);
-                    if (grid) {                                     // same for every lane: the cell of the accepted corner takes its index
-                        const int c = fyc * gw + fxc, n = gcnt[c];
-                        if (n < CELL_CAP && nacc < ACC_MAX) { if (l == first) { gent[c * CELL_CAP + n] = (unsigned short)nacc; gcnt[c] = (unsigned char)(n + 1); } }
-                        else grid = false;                          // from here on: the walk over all accepted corners
-                    }
-                    if (l == first) {
-                        if (nacc < ACC_MAX) { ax[nacc] = (short)x; ay[nacc] = (short)y; acx[nacc] = (short)xc; acy[nacc] = (short)yc; }
-                        if (nacc < a.cap) { a.out_xy[2 * nacc] = (float)x; a.out_xy[2 * nacc + 1] = (float)y; }
-                        alive = false;
-                    }
+                    accm |= 1ull << first;
                     nacc++;
+                    if (l == first) alive = false;
                     if (alive && filter) {
-                        const int dxc = fxc - xc, dyc = fyc - yc;
-                        if (dxc >= -1 && dxc <= 1 && dyc >= -1 && dyc <= 1) {
-                            const float dx = (float)(x - fx), dy = (float)(y - fy);
-                            if ((double)(dx * dx + dy * dy) < md2) alive = false;
-                        }
+                        const float dx = (float)(x - fx), dy = (float)(y - fy);
+                        if ((double)(dx * dx + dy * dy) < md2) alive = false;
                     }
                     m = __ballot(alive);
                     if (nacc >= ACC_MAX && filter) { overflow = true; break; }
                 }
+                // … then the batch's accepted corners enter the tables together (their order inside a cell does not matter)
+                bool full = false;
+                if ((accm >> l) & 1ull) {
+                    const int k = nacc0 + __popcll(accm & ((1ull << l) - 1ull));
+                    if (k < ACC_MAX) { ax[k] = (short)x; ay[k] = (short)y; acx[k] = (short)xc; acy[k] = (short)yc; }
+                    if (k < a.cap) { a.out_xy[2 * k] = (float)x; a.out_xy[2 * k + 1] = (float)y; }
+                    if (grid) {
+                        const int c = yc * gw + xc;
+                        const unsigned n = k < ACC_MAX ? atomicAdd(&gcnt[c], 1u) : (unsigned)CELL_CAP;
+                        if (n < (unsigned)CELL_CAP) gent[c * CELL_CAP + n] = (unsigned short)k;
+                        else full = true;
+                    }
+                }
+                if (__ballot(full)) grid = false;                   // a fifth corner in one cell: from here on the walk over all accepted corners
                 if (overflow) break;
                 __threadfence_block(); __builtin_amdgcn_wave_barrier();      // one wavefront: its LDS operations complete in order
             }
@@ -1164,10 +1178,8 @@ void enqueue_gftt(lvi_tracker* t, int32_t max_corners, bool lds_form)
     a.keysA = t->sort.keysA; a.valsA = t->sort.valsA; a.d_n = t->d_n; a.d_nbits = t->d_nbits; a.quality = t->P.gftt_quality;
     const int nblk = div_up(npx, CAND_TILE);
     LVI_LAUNCH(t->ctx, "gftt_mineig", 2.0 * npx + 4.0 * npx, hipLaunchKernelGGL(mineig_kernel, dim3(div_up(w, 32), div_up(h, 8)), dim3(256), 0, t->ctx.stream, a));
-    LVI_LAUNCH(t->ctx, "gftt_thr", 0, hipLaunchKernelGGL(gftt_thr_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, div_up(w, 32) * div_up(h, 8)));
-    LVI_LAUNCH(t->ctx, "gftt_count", 5.0 * npx, hipLaunchKernelGGL(gftt_count_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
-    LVI_LAUNCH(t->ctx, "gftt_scan", 0, hipLaunchKernelGGL(gftt_scan_kernel, dim3(1), dim3(256), 0, t->ctx.stream, a, nblk));
-    LVI_LAUNCH(t->ctx, "gftt_emit", 5.0 * npx, hipLaunchKernelGGL(gftt_emit_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a));
+    LVI_LAUNCH(t->ctx, "gftt_count", 5.0 * npx, hipLaunchKernelGGL(gftt_count_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a, div_up(w, 32) * div_up(h, 8)));
+    LVI_LAUNCH(t->ctx, "gftt_emit", 5.0 * npx, hipLaunchKernelGGL(gftt_emit_kernel, dim3(nblk), dim3(256), 0, t->ctx.stream, a, nblk));
     PickArgs p{};
     p.keysA = t->sort.keysA; p.valsA = t->sort.valsA; p.valsB = t->sort.valsB; p.d_nbits = t->d_nbits; p.total = t->d_total;
     p.w = w; p.h = h; p.max_corners = max_corners; p.cap = t->P.max_features; p.min_dist = t->P.min_dist;
