@@ -35,7 +35,6 @@ struct GridArgs {
     int* cell_start[2];
     lvi_pt* sorted[2];
     int* count[2];                 // [max_cells + 1] points per cell, zero between builds
-    int* cursor[2];                // [max_cells + 1] scatter cursors
     int* blockSum[2];              // [GRID_SCAN_BLOCKS]
     int cap, max_cells;
     int* d_status;
@@ -43,11 +42,10 @@ struct GridArgs {
 
 // d_status[1] is the status word of the map build: every build rewrites it (the scan-side word d_status[0] is cleared by
 // the scan upload, which may come before or after the build on the stream)
-__device__ int grid_meta_one(const GridArgs& a, int w)
+__device__ int grid_meta_one(const GridArgs& a, int w, GridIndex::Meta& m)
 {
-    GridIndex::Meta& m = *a.meta[w];
     const int n = a.nout[w];
-    m.n = n; m.ok = 0;
+    m.n = n; m.ok = 0; m.R = 1; m.edge = 0.5; m.inv_edge = 2.0;
     m.dim[0] = m.dim[1] = m.dim[2] = 1; m.ncells = 1; m.origin[0] = m.origin[1] = m.origin[2] = 0.0;
     if (n <= 0 || a.vox[w].n_valid == 0) return 0;
     double lo[3], ext[3];
@@ -71,15 +69,6 @@ __device__ int grid_meta_one(const GridArgs& a, int w)
     return 0;
 }
 
-__global__ void grid_meta_kernel(Batch<GridArgs> B_)
-{
-    const GridArgs& a = B_.a[blockIdx.z];
-    __shared__ int err[2];
-    if (threadIdx.x < 2) err[threadIdx.x] = grid_meta_one(a, threadIdx.x);
-    __syncthreads();
-    if (threadIdx.x == 0) a.d_status[1] = err[0] | err[1];
-}
-
 __device__ __forceinline__ void cell_of(const GridIndex::Meta& m, float x, float y, float z, int c[3])
 {
     // the same expression places the map points (grid_keys) and the queries (knn5_search_group)
@@ -99,8 +88,14 @@ __device__ __forceinline__ int cell_id_of(const GridIndex::Meta& m, const lvi_pt
 
 // The index is a counting sort by cell WITHOUT a stable order: the 5-NN result is a minimum over a total order
 // of (distance, index) keys, so the order of the points inside a cell cannot change it.  count → exclusive scan
-// (two kernels, GRID_SCAN_BLOCKS chunks) → scatter through per-cell cursors.  Every kernel is a grid-stride
-// loop over device-side counts: the launch geometry does not depend on the (device-only) map size.
+// (two kernels, GRID_SCAN_BLOCKS chunks) → scatter.  Every kernel is a grid-stride loop over device-side counts: the
+// launch geometry does not depend on the (device-only) map size.
+// Round 3: (1) the grid's geometry is derived by every workgroup of the count kernel itself (it follows from the map's bounding box:
+// a few hundred cycles; the one-thread kernel in front of the chain was 5 us of every map build) — the first workgroup of a
+// segment leaves it in global memory for the kernels behind; (2) no cursor array: the scan writes start(c) into cell_start[c + 1]
+// and the scatter advances THAT word, which ends as start(c) + count(c) = start(c + 1) — the array the search reads, with
+// cell_start[0] = 0 (2.6 MB less written per build, 2.6 MB less memory per slot); (3) the geometry is held in registers inside
+// the point loops (behind an atomic the compiler re-read origin / inv_edge / dim from global memory for every point).
 constexpr int GRID_PT_BLOCKS = 512;
 constexpr int GRID_SCAN_BLOCKS = 1024;
 
@@ -108,37 +103,53 @@ __global__ __launch_bounds__(256) void grid_count_kernel(Batch<GridArgs> B_)
 {
     const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
-    const GridIndex::Meta& m = *a.meta[w];
+    __shared__ GridIndex::Meta sm[2];
+    __shared__ int serr[2];
+    const bool lead = blockIdx.x == 0 && w == 0;                  // this workgroup also reports the build's status word
+    if (threadIdx.x == 0) serr[w] = grid_meta_one(a, w, sm[w]);
+    if (threadIdx.x == 64 && lead) serr[1] = grid_meta_one(a, 1, sm[1]);
+    __syncthreads();
+    const GridIndex::Meta m = sm[w];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.meta[w] = m;
+    if (lead && threadIdx.x == 0) a.d_status[1] = serr[0] | serr[1];
     if (!m.ok) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m.n; i += gridDim.x * 256) atomicAdd(&a.count[w][cell_id_of(m, a.ds[w][i])], 1);
 }
 
-// chunk b of the ncells + 1 entries: its total
+// chunk b of the ncells entries: its total
 __global__ __launch_bounds__(256) void grid_scan_sum_kernel(Batch<GridArgs> B_)
 {
     const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
-    const GridIndex::Meta& m = *a.meta[w];
-    const int total = m.ncells + 1;
-    const int L = (total + GRID_SCAN_BLOCKS - 1) / GRID_SCAN_BLOCKS;
-    const int c0 = blockIdx.x * L, c1 = min(total, c0 + L);
+    const int ncells = a.meta[w]->ncells, ok = a.meta[w]->ok;
+    const int L = (ncells + GRID_SCAN_BLOCKS - 1) / GRID_SCAN_BLOCKS;
+    const int c0 = blockIdx.x * L, c1 = min(ncells, c0 + L);
     int v = 0;
-    for (int c = c0 + threadIdx.x; c < c1; c += 256) v += (c < m.ncells && m.ok) ? a.count[w][c] : 0;
+    if (ok) {
+        for (int c = c0 + threadIdx.x; c < c1; c += 8 * 256) {      // eight loads in flight
+            int t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = a.count[w][min(c + u * 256, max(c1 - 1, 0))];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v += c + u * 256 < c1 ? t[u] : 0;
+        }
+    }
     __shared__ int ws[8];
     int tot;
     (void)block_excl_scan<256>(v, ws, &tot);
     if (threadIdx.x == 0) a.blockSum[w][blockIdx.x] = tot;
 }
 
-// cell_start[c] = points in cells < c, for c in [0, ncells]; cursor = the same; count back to zero
+// cell_start[0] = 0, cell_start[c + 1] = points in cells < c (the scatter's cursor of cell c; start(c + 1) once the scatter is through);
+// count back to zero
 __global__ __launch_bounds__(256) void grid_scan_apply_kernel(Batch<GridArgs> B_)
 {
     const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
-    const GridIndex::Meta& m = *a.meta[w];
-    const int total = m.ncells + 1;
-    const int L = (total + GRID_SCAN_BLOCKS - 1) / GRID_SCAN_BLOCKS;
-    const int c0 = blockIdx.x * L, c1 = min(total, c0 + L);
+    const int ncells = a.meta[w]->ncells, ok = a.meta[w]->ok;
+    const int L = (ncells + GRID_SCAN_BLOCKS - 1) / GRID_SCAN_BLOCKS;
+    const int c0 = blockIdx.x * L, c1 = min(ncells, c0 + L);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.cell_start[w][0] = 0;
     if (c0 >= c1) return;
     __shared__ int ws[8];
     int carry;
@@ -147,14 +158,16 @@ __global__ __launch_bounds__(256) void grid_scan_apply_kernel(Batch<GridArgs> B_
         for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) v += a.blockSum[w][j];
         (void)block_excl_scan<256>(v, ws, &carry);
     }
+    int* __restrict__ cnt = a.count[w];
+    int* __restrict__ cs = a.cell_start[w];
     for (int base = c0; base < c1; base += 256) {
         const int c = base + threadIdx.x;
-        const bool live = c < c1 && c < m.ncells && m.ok;
-        const int v = live ? a.count[w][c] : 0;
+        const bool live = c < c1 && ok;
+        const int v = live ? cnt[c] : 0;
         int tot;
         const int ex = carry + block_excl_scan<256>(v, ws, &tot);
-        if (c < c1) { a.cell_start[w][c] = ex; a.cursor[w][c] = ex; }
-        if (live) a.count[w][c] = 0;
+        if (c < c1) cs[c + 1] = ex;
+        if (live && v) cnt[c] = 0;                                 // (most cells are empty: nothing to write back)
         carry += tot;
     }
 }
@@ -163,13 +176,15 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(Batch<GridArgs> B_)
 {
     const GridArgs& a = B_.a[blockIdx.z];
     const int w = blockIdx.y;
-    const GridIndex::Meta& m = *a.meta[w];
+    const GridIndex::Meta m = *a.meta[w];
     if (!m.ok) return;
+    int* __restrict__ cs = a.cell_start[w];
+    lvi_pt* __restrict__ sorted = a.sorted[w];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < m.n; i += gridDim.x * 256) {
         lvi_pt p = a.ds[w][i];
-        const int pos = atomicAdd(&a.cursor[w][cell_id_of(m, p)], 1);
+        const int pos = atomicAdd(&cs[cell_id_of(m, p) + 1], 1);
         p.intensity = __int_as_float(i);        // original index in laserCloud*FromMapDS
-        a.sorted[w][pos] = p;
+        sorted[pos] = p;
     }
 }
 
@@ -1568,7 +1583,7 @@ static GridArgs grid_args(LidarDev& d)
     GridArgs g{};
     for (int w = 0; w < 2; w++) {
         g.meta[w] = d.grid[w].meta; g.cell_start[w] = d.grid[w].cell_start; g.sorted[w] = d.grid[w].sorted;
-        g.count[w] = d.grid[w].count; g.cursor[w] = d.grid[w].cursor; g.blockSum[w] = d.grid[w].blockSum;
+        g.count[w] = d.grid[w].count; g.blockSum[w] = d.grid[w].blockSum;
     }
     g.vox = d.voxMap.d_grid; g.nout = d.voxMap.d_nout;
     g.ds[0] = d.mapCornerDS; g.ds[1] = d.mapSurfDS;
@@ -1629,7 +1644,6 @@ void stage_map_index(const Slots& sl, const Ctx& cx)
     for (int z = 0; z < sl.n; z++) { G.a[z] = grid_args(sl[z]); nds += 0.02 * ((double)sl[z].n_map_corner + (double)sl[z].n_map_surf); }   // nominal DS size, byte accounting only
     for (int z = sl.n; z < MAX_BATCH; z++) G.a[z] = G.a[0];
     const unsigned S = (unsigned)sl.n;
-    LVI_LAUNCH(cx, "grid_meta", 0, hipLaunchKernelGGL(grid_meta_kernel, dim3(1, 1, S), dim3(64), 0, cx.stream, G));
     LVI_LAUNCH(cx, "grid_count", 16.0 * nds, hipLaunchKernelGGL(grid_count_kernel, dim3(GRID_PT_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
     LVI_LAUNCH(cx, "grid_scan_sum", 0, hipLaunchKernelGGL(grid_scan_sum_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));
     LVI_LAUNCH(cx, "grid_scan_apply", 0, hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GRID_SCAN_BLOCKS, 2, S), dim3(256), 0, cx.stream, G));

@@ -39,7 +39,7 @@ struct IcpState {                        // device, one per handle
 
 struct GridIndex {                       // uniform 0.5 m grid over one DS map (a-6 replacement for the kd-tree)
     int* cell_start = nullptr;           // [max_cells + 2]
-    int *count = nullptr, *cursor = nullptr;   // [max_cells + 2] points per cell (zero between builds), scatter cursors
+    int* count = nullptr;                // [max_cells + 2] points per cell (zero between builds)
     int* blockSum = nullptr;             // [1024] chunk totals of the cell scan
     lvi_pt* sorted = nullptr;            // [cap] xyz + original DS index in the intensity slot (as int bits)
     struct Meta { double origin[3]; double edge, inv_edge; int dim[3]; int ncells; int n; int ok; int R; }* meta = nullptr;   // device

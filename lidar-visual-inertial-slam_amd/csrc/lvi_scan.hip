@@ -905,12 +905,11 @@ void layout(AR& ar, LidarDev& d)
         d.voxMap.d_wprefix = d.map_owner->voxMap.d_wprefix;
     } else {                                            // every slot takes its own plan inside every re-voxelisation (the default)
         d.voxMap.d_binCountCached = ar.template alloc<unsigned>((size_t)2 * VB_NB);
-        d.voxMap.d_wprefix = ar.template alloc<unsigned>((size_t)2 * VB_WG * VB_NB);
+        d.voxMap.d_wprefix = ar.template alloc<unsigned>((size_t)2 * VB_WG * VB_WROW);
     }
     for (int w = 0; w < 2; w++) {
         d.grid[w].cell_start = ar.template alloc<int>((size_t)d.max_cells + 2);
         d.grid[w].count = ar.template alloc<int>((size_t)d.max_cells + 2);
-        d.grid[w].cursor = ar.template alloc<int>((size_t)d.max_cells + 2);
         d.grid[w].blockSum = ar.template alloc<int>(1024);
         d.grid[w].sorted = ar.template alloc<lvi_pt>(d.map_cap);
         d.grid[w].meta = ar.template alloc<GridIndex::Meta>(1);

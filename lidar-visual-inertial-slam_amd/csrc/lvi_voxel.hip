@@ -645,8 +645,8 @@ __global__ __launch_bounds__(256) void vb_plan_kernel(Batch<VoxArgs> B_)
         if (smiss && i0 < i1) atomicOr(&a.planMiss[s], 1);
         if (!spec && w == 0) atomicOr(&a.planMiss[s], 1);
     }
-    unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_NB;
-    for (int b = threadIdx.x; b < nbins; b += 256) row[b] = cnt[b];
+    unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_WROW;
+    if (i0 < i1) for (int b = threadIdx.x; b < nbins; b += 256) row[b] = cnt[b];       // (rows of empty ranges are never read)
 }
 
 __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
@@ -656,12 +656,13 @@ __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
     const int n = a.d_n[s];
     const VoxGrid& g = a.grid[s];
     if (a.plan_spec && g.plan_ok) return;           // vb_plan's counts stand
+    const int K = vb_wg_points(n);
+    const int i0 = w * K, i1 = min(n, i0 + K);
+    if (i0 >= i1) return;                           // (rows of empty ranges are never read)
     __shared__ unsigned cnt[VB_NB];
     const int nbins = g.nbins, sh = g.bin_shift;
     for (int b = threadIdx.x; b < nbins; b += 256) cnt[b] = 0u;
     __syncthreads();
-    const int K = vb_wg_points(n);
-    const int i0 = w * K, i1 = min(n, i0 + K);
     const int off = a.dyn[s].in_off;
     const lvi_pt* __restrict__ in = a.st[s].in + off;
     const uint8_t* __restrict__ mask = a.st[s].mask ? a.st[s].mask + off : nullptr;
@@ -675,47 +676,44 @@ __global__ __launch_bounds__(256) void vb_hist_w_kernel(Batch<VoxArgs> B_)
         }
     }
     __syncthreads();
-    unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_NB;
+    unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_WROW;
     for (int b = threadIdx.x; b < nbins; b += 256) row[b] = cnt[b];
 }
 
-// per bin: exclusive prefix over the workgroups (in place) and the bin's total.  64 bins x 4 quarters of the workgroup range per
-// workgroup of this kernel: a quarter's column is summed (loads 8 deep), the quarters meet in LDS, then each writes its prefixes
-// (one column walked by ONE thread was 512 dependent steps: 65 us for eight slots)
+// per bin: exclusive prefix over the workgroups (in place) and the bin's total.  16 bins x 16 parts of the workgroup range per
+// workgroup of this kernel: a part's column piece (32 rows) is loaded at once, summed, the parts meet in LDS, then each writes its
+// prefixes from the values it still holds (one column walked by ONE thread was 512 dependent steps: 65 us for eight slots; four
+// quarters with a second read of the column: 40 us; only the workgroups of live bins do anything)
 __global__ __launch_bounds__(256) void vb_colscan_kernel(Batch<VoxArgs> B_)
 {
     const VoxArgs& a = B_.a[blockIdx.z];
     unsigned* totals = a.binCountOut;
     const int s = blockIdx.y;
-    const int b = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;     // 4 parts of VB_WG / 4 workgroups each
-    constexpr int PW = VB_WG / 4;
-    __shared__ unsigned psum[4][64];
+    constexpr int NP = 16, PW = VB_WG / NP;                              // parts, rows per part
+    static_assert(PW == 32, "a part's rows are held in 32 registers");
+    const int b = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    __shared__ unsigned psum[NP][16];
     const bool live = b < VB_NB && b < a.grid[s].nbins;
-    unsigned* col = a.wprefix + (size_t)s * VB_WG * VB_NB + (live ? b : 0);
+    unsigned* col = a.wprefix + (size_t)s * VB_WG * VB_WROW + (live ? b : 0) + (size_t)part * PW * VB_WROW;
+    // rows of workgroups whose point range is empty are neither written (vb_plan, vb_hist_w) nor read (vb_scatter_det): the corner map
+    // of the bench — 4 096 bins, fifteen active workgroups — was 8 MB of zeros read and written per slot
+    const int n = a.d_n[s];
+    const int nrow = min(VB_WG, (n + vb_wg_points(n) - 1) / vb_wg_points(n)) - part * PW;      // active rows of this part
+    unsigned v[PW];
     unsigned acc = 0u;
-    if (live) {
-        for (int w0 = part * PW; w0 < (part + 1) * PW; w0 += 8) {
-            unsigned v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = col[(size_t)(w0 + u) * VB_NB];
+    for (int u = 0; u < PW; u++) v[u] = (live && u < nrow) ? col[(size_t)u * VB_WROW] : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc += v[u];
-        }
-    }
-    psum[part][threadIdx.x & 63] = acc;
+    for (int u = 0; u < PW; u++) acc += v[u];
+    psum[part][threadIdx.x & 15] = acc;
     __syncthreads();
     unsigned before = 0u, total = 0u;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const unsigned t = psum[q][threadIdx.x & 63]; before += q < part ? t : 0u; total += t; }
+    for (int q = 0; q < NP; q++) { const unsigned t = psum[q][threadIdx.x & 15]; before += q < part ? t : 0u; total += t; }
     if (live) {
         unsigned run = before;
-        for (int w0 = part * PW; w0 < (part + 1) * PW; w0 += 8) {
-            unsigned v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = col[(size_t)(w0 + u) * VB_NB];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { col[(size_t)(w0 + u) * VB_NB] = run; run += v[u]; }
-        }
+        for (int u = 0; u < PW; u++) { if (u < nrow) col[(size_t)u * VB_WROW] = run; run += v[u]; }
     }
     if (part == 0 && b < VB_NB) totals[(size_t)s * VB_NB + b] = live ? total : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.plan_spec) a.planMiss[s] = 0;      // consumed (vox_setup read it): the next run's vb_plan starts clean
@@ -733,7 +731,7 @@ __global__ __launch_bounds__(256) void vb_scatter_det_kernel(Batch<VoxArgs> B_)
     __shared__ unsigned cnt[VB_NB], pos[VB_NB];
     const int nbins = g.nbins, sh = g.bin_shift;
     const int* bs = a.binStart + (size_t)s * (VB_NB + 1);
-    const unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_NB;
+    const unsigned* row = a.wprefix + ((size_t)s * VB_WG + w) * VB_WROW;
     for (int b = threadIdx.x; b < nbins; b += 256) { cnt[b] = 0u; pos[b] = (unsigned)bs[b] + row[b]; }
     __syncthreads();
     const int off = a.dyn[s].in_off;
@@ -1517,7 +1515,7 @@ void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& p, const char* tag, double
     if (voxel_resolve_mode(p) == VOX_BINNED && p.d_binCountCached) {
         LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, 1), dim3(64), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[2], 16.0 * n_hint, hipLaunchKernelGGL(vb_hist_w_kernel, dim3(VB_WG, p.nseg, 1), dim3(256), 0, ctx.stream, B));
-        hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 64, p.nseg, 1), dim3(256), 0, ctx.stream, B);
+        hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 16, p.nseg, 1), dim3(256), 0, ctx.stream, B);
         LVI_HIP(hipGetLastError());
         p.hist_cached = true;
     }
@@ -1578,7 +1576,7 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
         LVI_LAUNCH(ctx, "vb_plan/map", 16.0 * n_hint, hipLaunchKernelGGL(vb_plan_kernel, dim3(VB_WG, p.nseg, S), dim3(256), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, nm[1], 0, hipLaunchKernelGGL(vox_setup_kernel, dim3(p.nseg, 1, S), dim3(64), 0, ctx.stream, B));
         LVI_LAUNCH(ctx, "vb_hist_w/map", 0, hipLaunchKernelGGL(vb_hist_w_kernel, dim3(VB_WG, p.nseg, S), dim3(256), 0, ctx.stream, B));
-        LVI_LAUNCH(ctx, "vb_colscan/map", 0, hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 64, p.nseg, S), dim3(256), 0, ctx.stream, B));
+        LVI_LAUNCH(ctx, "vb_colscan/map", 0, hipLaunchKernelGGL(vb_colscan_kernel, dim3(VB_NB / 16, p.nseg, S), dim3(256), 0, ctx.stream, B));
     } else {
         for (int z = 0; z < S; z++) B.a[z].plan_spec = 0;
         if (!cached) LVI_LAUNCH(ctx, nm[0], 16.0 * n_hint, hipLaunchKernelGGL(vox_minmax_kernel, dim3(p.nblk_mm, p.nseg, S), dim3(256), 0, ctx.stream, B));
@@ -1586,7 +1584,7 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
     }
     if (mode == VOX_BINNED) {
         const dim3 gt(div_up(p.seg_cap, VB_STILE), p.nseg, S);
-        const dim3 gb(std::max(64, std::min(div_up(p.seg_cap, 2048), VB_ACC_BLOCKS)), p.nseg, S);       // grid-stride over the bins
+        const dim3 gb(std::max(512, std::min(div_up(p.seg_cap, 2048), VB_ACC_BLOCKS)), p.nseg, S);      // grid-stride over the bins (a workgroup per bin or two: a bin is three dependent steps)
         const dim3 gh2(std::min(div_up(p.seg_cap, VB_TILE), 512), p.nseg, S);
         bool hist_cached = true;
         for (int z = 0; z < S; z++) hist_cached = hist_cached && B.a[z].binCountCached != nullptr;

@@ -45,6 +45,7 @@ constexpr int VB_TILE = 4096;    // binned path: points per tile of the histogra
 constexpr int VB_STILE = 4096;   // binned path: points per workgroup of the scatter kernel (2048: 62 us instead of 56 us for the 4.9 M-point map)
 constexpr int VB_PAD = 1;        // binned path: stride of the global bin counters / cursors (one per 64-B line, VB_PAD = 16, measured SLOWER: hist 36 vs 29 us, scatter 67 vs 56 us)
 constexpr int VB_WG = 512;       // deterministic partition: workgroups (= contiguous point ranges) per segment (256 / 512 / 1024: scatter 62 / 44 / 46 us on the 4.87 M-point map)
+constexpr int VB_WROW = VB_NB + 64;   // words per row of the per-(workgroup, bin) count table: NOT a power of two — vb_colscan walks columns, and rows 16 KB apart meet in the same memory channels
 constexpr int VB_CH = 8192;       // binned path: points per accumulate workgroup (chunk of a bin); with 32 scans in flight 4096 / 8192 / 16384: 7 050 / 7 400 / 7 460 scans/s (one rebuild alone: accum 33 / ~40 / 50 us)
 constexpr int VB_LIGHT = 256;     // binned path: a bin of at most this many points is accumulated by ONE wavefront (vb_light_kernel)
 constexpr int VB_TAB = 1 << VB_CL_LOG;      // entries per compacted chunk table
