@@ -49,5 +49,6 @@ node = H.TrackerNode(hl, tp, h, w, 1000, equalize=True, cam=cam, device=0)
 ts = []
 for i in range(n):
     t0 = time.perf_counter(); r = node.image(frames[i % 5], 5.0 + 0.01 * i); ts.append(time.perf_counter() - t0)
-print("us per frame (median of the last half):", 1e6 * float(np.median(ts[n // 2:])), "features", int(r["n_cur_pts"]))
+blocks = [1e6 * float(np.median(ts[i:i + 100])) for i in range(100, n - 99, 100)] or [1e6 * float(np.median(ts[n // 2:]))]
+print("us per frame: best 100-frame block %.1f, median block %.1f, worst %.1f (%d blocks); features %d" % (min(blocks), float(np.median(blocks)), max(blocks), len(blocks), int(r["n_cur_pts"])))
 node.close()
