@@ -339,17 +339,21 @@ __device__ __forceinline__ uint64_t bits_from(const uint64_t* words, int pos)
     return sh ? ((lo >> sh) | (words[wi + 1] << (64 - sh))) : lo;
 }
 
+#define CV(j) s_curv[(j) + ((j) >> 4)]
 __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArgs> B_)
 {
     const FeatArgs& a = B_.a[blockIdx.z];
-    __shared__ float s_curv[FEAT_SEG_CAP + 32];
-    __shared__ uint8_t s_pick[FEAT_SEG_CAP + 16], s_reach[FEAT_SEG_CAP + 16];
+    __shared__ float s_curv[FEAT_SEG_CAP + 32 + (FEAT_SEG_CAP + 32) / 16 + 2];      // padded: one word behind every 16 (CV below) — a thread's 16 contiguous values
+                                                                                     // no longer sit in two banks for the whole wavefront (the static part of a sector was 32-way conflicts)
+    __shared__ __attribute__((aligned(16))) uint8_t s_pick[FEAT_SEG_CAP + 16];     // (16-byte aligned: a thread reads its chunk of 16 in one access)
+    __shared__ __attribute__((aligned(16))) uint8_t s_reach[FEAT_SEG_CAP + 16];
     __shared__ int8_t s_label[FEAT_SEG_CAP + 16];
     __shared__ uint64_t s_brk[FEAT_SEG_CAP / 64 + 2];         // bit j: column jump (or cloud edge) between j-1 and j
     __shared__ unsigned s_UL[FEAT_THREADS + 4];               // per thread chunk of 16 points: undecided bits (low half) and labelled bits (high half) in ONE word,
                                                               // so that a neighbour reads a consistent pair (+1 pad in front)
     __shared__ unsigned short s_cand[FEAT_SEG_CAP];           // corner candidates (local indices); their order key is (curvature bits, index)
     __shared__ unsigned short s_sorted[FEAT_SEG_CAP];         // candidates by descending key
+    __shared__ unsigned short s_cs[FEAT_SEG_CAP + 16];        // corner walk: the candidates of the 64-lane batch in flight, by position (zero outside a batch)
     __shared__ int s_ws[FEAT_THREADS / 64 + 2];
     __shared__ int s_anyr[3], s_timeout;
 
@@ -374,7 +378,8 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
 
     if (tid < 4) s_UL[tid == 0 ? 0 : FEAT_THREADS + tid] = 0;
     if (tid == 0) { s_brk[FEAT_SEG_CAP / 64] = ~0ull, s_brk[FEAT_SEG_CAP / 64 + 1] = ~0ull; s_timeout = 0; }
-    for (int j = FEAT_SEG_CAP + tid; j < FEAT_SEG_CAP + 32; j += FEAT_THREADS) s_curv[j] = 0.f;
+    for (int j = FEAT_SEG_CAP + tid; j < FEAT_SEG_CAP + 32; j += FEAT_THREADS) CV(j) = 0.f;
+    for (int j = tid; j < FEAT_SEG_CAP + 16; j += FEAT_THREADS) s_cs[j] = 0;
     __syncthreads();
 
     const int sR = a.startR[ring], eR = a.endR[ring];
@@ -393,11 +398,16 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
         if (!bounds(sec, sp, ep)) return;
         const int k0 = sp - 5, L = ep - sp + 11;
 #pragma unroll
+        for (int i = 0; i < FEAT_EPT; i++) {        // unconditional loads from a clamped index (behind `in ? … : …` every load waited for the one before it:
+            const int j = tid + i * FEAT_THREADS, k = k0 + j;         // 32 round trips at the head of a ring's first sector), lanes masked afterwards
+            const int kc = min(max(k, 0), max(n - 1, 0));
+            pf_cv[i] = a.curv[kc]; pf_fl[i] = a.pflags[kc];
+        }
+#pragma unroll
         for (int i = 0; i < FEAT_EPT; i++) {
             const int j = tid + i * FEAT_THREADS, k = k0 + j;
             const bool in = (j < L && k >= 0 && k < n);
-            pf_cv[i] = in ? a.curv[k] : 0.f;
-            pf_fl[i] = in ? a.pflags[k] : (uint8_t)3;
+            pf_cv[i] = in ? pf_cv[i] : 0.f; pf_fl[i] = in ? pf_fl[i] : (uint8_t)3;
         }
     };
     // pipelined only for up to 4 rings (24 workgroups, each owning a CU's LDS): with many more, several such kernels in flight
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
 #pragma unroll
         for (int i = 0; i < FEAT_EPT; i++) {
             const int j = tid + i * FEAT_THREADS;
-            s_curv[j] = pf_cv[i]; s_pick[j] = (uint8_t)(pf_fl[i] & 1u); s_label[j] = 0;
+            CV(j) = pf_cv[i]; s_pick[j] = (uint8_t)(pf_fl[i] & 1u); s_label[j] = 0;
             const uint64_t m = __ballot((pf_fl[i] >> 1) & 1u);
             if (lane_id() == 0) s_brk[j >> 6] = m;
         }
@@ -465,9 +475,11 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
         unsigned short pat[FEAT_EPT];
         unsigned statc = 0;                                              // bit i: point jb+i is in [jlo, jhi] with curvature < surfThreshold
         {
+            const uint4 rch4 = *reinterpret_cast<const uint4*>(&s_reach[jb]);      // the chunk's 16 reach bytes in one aligned read
+            const unsigned rch[4] = {rch4.x, rch4.y, rch4.z, rch4.w};
             float cw[FEAT_EPT + 10];                                     // curvature of j = jb-5 … jb+20
 #pragma unroll
-            for (int q = 0; q < FEAT_EPT + 10; q++) { const int j = jb - 5 + q; cw[q] = (j >= 0) ? s_curv[j] : 0.f; }
+            for (int q = 0; q < FEAT_EPT + 10; q++) { const int j = jb - 5 + q; cw[q] = (j >= 0) ? CV(j) : 0.f; }
 #pragma unroll
             for (int i = 0; i < FEAT_EPT; i++) {
                 const int j = jb + i;
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
                 const bool cand = (j >= jlo && j <= jhi && cw[i + 5] < a.surfThreshold);
                 if (cand) {
                     const float cj = cw[i + 5];
-                    const int rc = s_reach[j];
+                    const int rc = (int)((rch[i >> 2] >> (8 * (i & 3))) & 255u);
                     const int f = rc & 15, bk = rc >> 4;
 #pragma unroll
                     for (int q = 1; q <= 5; q++) {
@@ -493,6 +505,16 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
                 pat[i] = (unsigned short)p;
             }
         }
+        // the patterns transposed: em[d + 5] bit i <-> "the neighbour at offset d of point jb + i is reachable and earlier in the walk"
+        // (static as well: formed here, before the hand-over wait, not between the two walks)
+        unsigned em[11];
+#pragma unroll
+        for (int d = 0; d < 11; d++) {
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < FEAT_EPT; i++) m |= (((unsigned)pat[i] >> d) & 1u) << i;
+            em[d] = m;
+        }
         // ---- corners.  The reference sorts [sp,ep) by curvature and walks ep, then the sorted range from
         // the top, taking a point if it is still unpicked (max 40) and marking its +-5 neighbours.
         // Here: compact the candidates (unpicked, curvature > edgeThreshold), rank-sort them in LDS, and
@@ -500,10 +522,10 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
         int ncand;
         {
             int mine = 0;
-            for (int j = jlo + tid; j < jhi; j += FEAT_THREADS) mine += (s_pick[j] == 0 && s_curv[j] > a.edgeThreshold) ? 1 : 0;
+            for (int j = jlo + tid; j < jhi; j += FEAT_THREADS) mine += (s_pick[j] == 0 && CV(j) > a.edgeThreshold) ? 1 : 0;
             int pos = block_excl_scan<FEAT_THREADS>(mine, s_ws, &ncand);
             for (int j = jlo + tid; j < jhi; j += FEAT_THREADS)
-                if (s_pick[j] == 0 && s_curv[j] > a.edgeThreshold) s_cand[pos++] = (unsigned short)j;
+                if (s_pick[j] == 0 && CV(j) > a.edgeThreshold) s_cand[pos++] = (unsigned short)j;
         }
         __syncthreads();
         LVI_STAMP(1);
@@ -512,11 +534,11 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
         // so that a sector workgroup leaves room on its CU for the map kernels of the other scans in flight
         for (int i = tid; i < ncand; i += FEAT_THREADS) {
             const int jm = s_cand[i];
-            const unsigned long long mine = ((unsigned long long)__float_as_uint(s_curv[jm]) << 32) | (unsigned)jm;
+            const unsigned long long mine = ((unsigned long long)__float_as_uint(CV(jm)) << 32) | (unsigned)jm;
             int rank = 0;
             for (int q = 0; q < ncand; q++) {
                 const int jq = s_cand[q];
-                rank += ((((unsigned long long)__float_as_uint(s_curv[jq]) << 32) | (unsigned)jq) > mine) ? 1 : 0;     // keys are unique (index in the low word)
+                rank += ((((unsigned long long)__float_as_uint(CV(jq)) << 32) | (unsigned)jq) > mine) ? 1 : 0;     // keys are unique (index in the low word)
             }
             s_sorted[rank] = (unsigned short)jm;
         }
@@ -557,28 +579,53 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
                 taken++;
             };
             // position ep is outside the sorted range and is visited first (:171,174)
-            if (jhi >= jlo && v_pick[jhi] == 0 && s_curv[jhi] > a.edgeThreshold) take(jhi);
+            if (jhi >= jlo && v_pick[jhi] == 0 && CV(jhi) > a.edgeThreshold) take(jhi);
+            // The walk takes the candidates in descending key order, a taken one marks the points within its reach, a marked one is
+            // skipped: the lexicographically first maximal independent set of the order.  64 candidates at a time (lane order = walk
+            // order), resolved in parallel rounds: a lane is IN once no EARLIER lane that covers it is still undecided or IN, OUT as soon
+            // as an earlier IN lane covers it (a later lane's marks come too late to matter to an earlier one).  The lowest undecided
+            // lane is always decided, two to four rounds in practice instead of one serial step per take (285 cycles each, 40 per sector:
+            // this walk was 40 % of a sector's part of the ring's critical path).  Decisions of earlier lanes never depend on later ones,
+            // so cutting the IN set at the 40-corner limit by lane order is the walk stopped at its 40th take.
             for (int base = 0; base < ncand && taken < CORNERS_PER_SECTOR; base += 64) {
                 const int j = (base + l < ncand) ? (int)s_sorted[base + l] : -1;
-                const int rcj = j >= 0 ? (int)s_reach[j] : 0;              // every lane brings its candidate's reach: the walk below reads no LDS
-                bool alive = j >= 0 && s_pick[j] == 0;
-                uint64_t m = __ballot(alive);
-                while (m && taken < CORNERS_PER_SECTOR) {
-                    const int first = __ffsll((long long)m) - 1;
-                    const int win = __builtin_amdgcn_readlane(j, first);          // `first` is wave-uniform: a scalar read, no LDS round trip
-                    const int rc = __builtin_amdgcn_readlane(rcj, first);
-                    // one store per lane 0..10 (the point and its +-5 neighbours within reach); this section runs on ONE wavefront,
-                    // whose LDS operations complete in order, so the plain s_pick is enough (no wait behind every volatile access)
-                    const int tgt = l <= 5 ? win + l : win - (l - 5);
-                    const bool wr = l <= 5 ? l <= (rc & 15) : (l <= 10 && l - 5 <= (rc >> 4));
-                    if (wr) s_pick[tgt] = 1;
-                    if (l == 0) { out_idx[taken] = k0 + win; s_label[win] = 1; }
-                    taken++;
-                    // a taken point kills exactly the candidates within its reach
-                    const int dj = j - win;
-                    if (dj == 0 || (dj > 0 && dj <= (rc & 15)) || (dj < 0 && -dj <= (rc >> 4))) alive = false;
-                    m = __ballot(alive);
+                const int rcj = j >= 0 ? (int)s_reach[j] : 0;
+                const bool alive = j >= 0 && s_pick[j] == 0;
+                const unsigned short mine = alive ? (unsigned short)((l + 1) | (rcj << 8)) : (unsigned short)0;     // bits 0-6 lane + 1, bit 7 IN, bits 8-15 reach
+                if (j >= 0) s_cs[j] = mine;
+                bool undec = alive, isin = false;
+                for (;;) {
+                    __threadfence_block(); __builtin_amdgcn_wave_barrier();      // one wavefront: its LDS operations complete in order
+                    bool blocked = false, killed = false;
+                    if (undec) {
+                        unsigned lo[5], hi[5];
+#pragma unroll
+                        for (int d = 1; d <= 5; d++) { lo[d - 1] = s_cs[j - d]; hi[d - 1] = s_cs[j + d]; }
+#pragma unroll
+                        for (int d = 1; d <= 5; d++) {
+                            const unsigned p = lo[d - 1], q = hi[d - 1];
+                            if (p && (int)(p & 127u) - 1 < l && d <= (int)((p >> 8) & 15u)) { if (p & 128u) killed = true; else blocked = true; }
+                            if (q && (int)(q & 127u) - 1 < l && d <= (int)(q >> 12)) { if (q & 128u) killed = true; else blocked = true; }
+                        }
+                    }
+                    const bool now_in = undec && !blocked && !killed, now_out = undec && killed;
+                    if (now_in) { isin = true; s_cs[j] = (unsigned short)(mine | 128u); }
+                    if (now_out) s_cs[j] = 0;                               // takes nothing, marks nothing, blocks nobody
+                    undec = undec && !now_in && !now_out;
+                    if (!__ballot(undec)) break;
                 }
+                const uint64_t inm = __ballot(isin);
+                const int room = CORNERS_PER_SECTOR - taken, nin = __popcll(inm);
+                const int rank = __popcll(inm & ((1ull << l) - 1ull));
+                if (isin && rank < room) {
+                    out_idx[taken + rank] = k0 + j; s_label[j] = 1;
+                    const int f = rcj & 15, bk = rcj >> 4;
+                    for (int q = 0; q <= f; q++) s_pick[j + q] = 1;
+                    for (int q = 1; q <= bk; q++) s_pick[j - q] = 1;
+                }
+                taken += min(nin, room);
+                if (j >= 0) s_cs[j] = 0;
+                __threadfence_block(); __builtin_amdgcn_wave_barrier();
             }
             if (l == 0) a.sector_cnt[ring * 6 + sec] = taken;
         }
@@ -602,18 +649,11 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
         // chunk's old or new bits are equally valid.
         unsigned myU = 0, myL = 0;
         {
+            const uint4 pk4 = *reinterpret_cast<const uint4*>(&s_pick[jb]);         // the chunk's 16 picked bytes in one aligned read
+            const unsigned pk[4] = {pk4.x, pk4.y, pk4.z, pk4.w};
 #pragma unroll
-            for (int i = 0; i < FEAT_EPT; i++) if (((statc >> i) & 1u) && s_pick[jb + i] == 0) myU |= 1u << i;      // candidates the corner walk left unpicked
+            for (int i = 0; i < FEAT_EPT; i++) if (((statc >> i) & 1u) && ((pk[i >> 2] >> (8 * (i & 3))) & 255u) == 0u) myU |= 1u << i;      // candidates the corner walk left unpicked
             s_UL[tid + 1] = myU;
-        }
-        // the patterns transposed: em[d + 5] bit i <-> "the neighbour at offset d of point jb + i is reachable and earlier in the walk"
-        unsigned em[11];
-#pragma unroll
-        for (int d = 0; d < 11; d++) {
-            unsigned m = 0;
-#pragma unroll
-            for (int i = 0; i < FEAT_EPT; i++) m |= (((unsigned)pat[i] >> d) & 1u) << i;
-            em[d] = m;
         }
         __syncthreads();
         LVI_STAMP(4);
@@ -705,6 +745,7 @@ __global__ __launch_bounds__(FEAT_THREADS) void feat_sector_kernel(Batch<FeatArg
 }
 
 // ---------------------------------------------------------------------------------------------
+#undef CV
 // a-3 for rings whose sectors do not fit the LDS-resident kernel (more than FEAT_SEG_CAP - 11 points per sector, e.g.
 // N_SCAN = 1 with > 49 k points): the same two walks over GLOBAL memory, one workgroup per ring, sectors in order (the marks
 // of a sector simply stay in picked[] for the next one).  Slow by design — tens of block-wide passes per sector — and exact:
