@@ -238,6 +238,7 @@ static void release_slot(LidarDev& d)
     d.voxRing.release(); d.voxScan.release(); d.voxMap.release(); d.voxGen.release();
     d.arena.release();
     if (d.h_icp) (void)hipHostFree(d.h_icp);
+    if (d.h_gn_feat) (void)hipHostFree(d.h_gn_feat);
     if (d.h_kfSeg) (void)hipHostFree(d.h_kfSeg);
     if (d.inc.h_pieces) (void)hipHostFree(d.inc.h_pieces);
     if (d.inc.h_status) (void)hipHostFree(d.inc.h_status);

@@ -19,6 +19,7 @@
 // accumulators; the NEXT launch reads the totals and every workgroup runs the 6x6 end of the iteration (QR solve, the
 // iteration-0 eigen analysis, pose update, convergence test) on them — no exchange inside a launch.
 #include <cstdlib>
+#include <type_traits>
 
 #include "lvi_lidar.hpp"
 
@@ -630,6 +631,7 @@ struct IcpArgs {
     unsigned char* fit_ok;                        // [cap] 0: no fit stored; 1: stored, geometric gate passed; 2: stored, gate failed
     float knn_slack;                              // metres added to the radius of a bounded search (room for later iterations to skip theirs)
     int lds_tiles;                                // LVI_KNN_TILES=1: phase A stages the index tile of a wavefront's features in LDS when it fits (4 lanes per feature; same bits; see DESIGN for why it is not the default)
+    int* h_feat;                                  // pinned host word: this match's feature count, for the next launches' grid (LidarDev::h_gn_feat)
     int stamp_iter;                               // the iteration whose phase stamps are kept in cyc[] (LVI_ICP_STAMP_ITER, default: the last one launched)
     int xcd_map;                                  // residual workgroups are dealt to the XCDs in contiguous feature ranges (LVI_ICP_NO_XCD_MAP=1: in launch order)
     // normal equations: 28 columns x {coarse, fine} exact fixed-point accumulators, ICP_SHARDS shards (workgroup & 7), three
@@ -1181,11 +1183,15 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
     const int Q = nC + nS;
     const int nb = (Q + QPB - 1) / QPB;
     const int per_xcd = (nb + 7) / 8;
-    const int wg = a.xcd_map ? (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if ((a.xcd_map && (int)(blockIdx.x >> 3) >= per_xcd) || wg >= nb) return;
-    const bool stamp = (wg == nb / 2 && threadIdx.x == 0 && (a.stamp_iter < 0 || a.stamp_iter == iter));      // a surf workgroup in the middle
-    long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
+    // The grid need not cover the features: a workgroup goes on to the block `stride` further (inside its XCD's share) until the scan's
+    // blocks are used up.  The host sizes the grid from the feature counts the last finished matches reported (gn_grid_features), not
+    // from the capacity: eight scans' worth of capacity were ~7 000 workgroups per launch that allocated registers and LDS to find out
+    // they had nothing to do (+2 % scans/s under four-handle load).  Any grid gives the same sums (exact integers, shard = block & 7).
+    int jx = a.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int jstride = a.xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int jlim = a.xcd_map ? per_xcd : nb;
+    const int jbase = a.xcd_map ? (int)(blockIdx.x & 7u) * per_xcd : 0;
+    if (jx >= jlim || jbase + jx >= nb) return;
     __shared__ float sA[12], sT[6];
     __shared__ __attribute__((aligned(16))) float srow[QPB][8];                  // the Gauss-Newton row of a feature: matA(i, 0..5), matB(i), selected (1 / 0)
     __shared__ long long spi[QPB / 16][56];         // exact fixed-point images (coarse, fine) of the sums of 16 consecutive features
@@ -1201,6 +1207,14 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
     constexpr int TP = FIRST ? 384 : 256, TC = FIRST ? 1024 : 768;      // points / cell starts of a wavefront's index tile (unit ball | bounded ball)
     __shared__ __attribute__((aligned(16))) KnnTile<TP, TC> stile[TILES ? NT / 64 : 1];      // (the tile form is a separate instantiation: LVI_KNN_TILES=1)
     __shared__ int sdone;
+    // (LDS is declared out here: a __shared__ variable inside the body below would exist once per instantiation)
+    // (the block body is instantiated twice — with the head of the launch for a workgroup's first block, without it for the blocks it
+    // walks on to: as ONE loop body the head's registers stayed live around the loop and the kernel spilled 250 bytes per lane)
+    auto run_block = [&](const int wg, auto first_tag) -> bool {
+    constexpr bool first = decltype(first_tag)::value;
+    const bool stamp = (wg == nb / 2 && threadIdx.x == 0 && (a.stamp_iter < 0 || a.stamp_iter == iter));      // a surf workgroup in the middle
+    long long t_prev = stamp ? clock64() : 0, t_first = t_prev, cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define LVI_STAMP(slot) do { if (stamp) { const long long t_now = clock64(); cyc[slot] += t_now - t_prev; t_prev = t_now; } } while (0)
     const bool use_prev = !FIRST && a.nn_prev != nullptr;
     const int cap = a.cap;
     constexpr unsigned PERM_ID = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
@@ -1227,7 +1241,8 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
             f1 = a.fit[tc]; f2 = a.fit2[tc]; fok = a.fit_ok[tc];
         }
     }
-    // ---- H: the end of iteration iter - 1
+    // ---- H: the end of iteration iter - 1 (once per workgroup: its first block)
+    if constexpr (first) {
     if constexpr (FIRST) {
         if (threadIdx.x < 12) sA[threadIdx.x] = poseA;
         if (threadIdx.x < 6) sT[threadIdx.x] = poseT;
@@ -1254,7 +1269,8 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
     // the buffer the NEXT launch adds into (last read by the previous launch)
     if (wg == 0) { unsigned long long* z = a.acc + (size_t)((iter + 1) % 3) * (ICP_SHARDS * 56); for (int k = threadIdx.x; k < ICP_SHARDS * 56; k += NT) z[k] = 0ull; }
     __syncthreads();
-    if (sdone) return;
+    if (sdone) return true;
+    }
     LVI_STAMP(0);
     // ---- phase 0, second half.  From the second iteration on a feature knows its previous five neighbours; their distances
     // under the new pose bound the fifth-nearest distance (five map points lie inside that ball), and the search either shrinks
@@ -1469,7 +1485,14 @@ __global__ __launch_bounds__(QPB == 64 ? 64 * G : 256, TILES ? 1 : 4) void icp_g
     }
     LVI_STAMP(4);
     if (stamp) { cyc[5] = clock64() - t_first; for (int q = 0; q < 8; q++) a.cyc[q] = cyc[q]; }
+    return false;
+    };
 #undef LVI_STAMP
+    if (run_block(jbase + jx, std::true_type{})) return;
+    for (jx += jstride; jx < jlim && jbase + jx < nb; jx += jstride) {
+        __syncthreads();                            // the previous block's LDS (rows, lists, sums) is done with
+        (void)run_block(jbase + jx, std::false_type{});
+    }
 }
 
 // After the last Gauss-Newton launch: the end of its iteration (unless the loop ended earlier), transformUpdate, the pose
@@ -1493,7 +1516,7 @@ __global__ __launch_bounds__(64) void icp_final_kernel(Batch<IcpArgs> B_, int n_
         (void)icp_iter_end(a, n_iters - 1, ssum, threadIdx.x, true, s.degenerate, P);
     }
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    if (threadIdx.x == 0) icp_finish_body(a);
+    if (threadIdx.x == 0) { icp_finish_body(a); if (a.h_feat) *a.h_feat = a.nq[0] + a.nq[1]; }
 }
 
 __global__ __launch_bounds__(256) void transform_kernel(const lvi_pt* in, int n, IcpPose pose, lvi_pt* out)
@@ -1555,7 +1578,7 @@ IcpArgs icp_args(LidarDev& d)
     a.cap = d.ext_cap; a.nn_pt = d.nnPt; a.fit = d.fitA; a.fit2 = d.fitB; a.fit_ok = d.fitOk; a.acc = d.icpAcc;
     a.nn_ref = (d.knn_bound && d.knn_skip) ? d.nnRef : nullptr; a.knn_slack = d.knn_slack;
     { static const bool no_map = getenv("LVI_ICP_NO_XCD_MAP") != nullptr; a.xcd_map = no_map ? 0 : 1; }
-    a.stamp_iter = d.icp_stamp_iter; a.lds_tiles = d.knn_tiles ? 1 : 0;
+    a.stamp_iter = d.icp_stamp_iter; a.lds_tiles = d.knn_tiles ? 1 : 0; a.h_feat = d.h_gn_feat;
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;
@@ -1797,6 +1820,23 @@ void set_pose_init(const Slots& sl, const float* p, bool clear_status)
 }
 void set_pose_init(LidarDev& d, const float p[6]) { set_pose_init(OneSlot(d).s, p, false); }
 
+// Features the GN launches' grid is sized for: what the last finished matches of these slots had (+ 1/8, + a block), or the capacity
+// while nothing is known.  A hint: the kernel walks on when a scan has more (LVI_GN_GRID=cap: always the capacity).
+static int gn_grid_features(const Slots& sl)
+{
+    const bool full = getenv("LVI_GN_GRID") != nullptr;
+    const LidarDev& d0 = sl.first();
+    if (const char* e = getenv("LVI_GN_GRID_FEATURES")) { const int f = atoi(e); if (f > 0) return std::min(d0.ext_cap, f); }      // tests: a grid far too small
+    int seen = 0;
+    for (int z = 0; z < sl.n; z++) {
+        const int v = sl[z].h_gn_feat ? *(volatile const int*)sl[z].h_gn_feat : 0;
+        if (v <= 0) return d0.ext_cap;                 // a slot that has not reported yet
+        seen = std::max(seen, v);
+    }
+    if (full || seen <= 0) return d0.ext_cap;
+    return std::min(d0.ext_cap, seen + seen / 8 + 256);
+}
+
 void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_records, int it_begin, int it_end)
 {
     LidarDev& d = sl.first();
@@ -1818,6 +1858,7 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
     const unsigned S = (unsigned)sl.n;
     const Ctx& cx = d.ctx;
     const int it_last = it_end < 0 ? a.max_iters : std::min(it_end, a.max_iters);
+    const int ext_cap_l = gn_grid_features(sl);
     for (int it = it_begin; it < it_last; it++) {
         // (the grid covers ext_cap features; the ~1 200 workgroups beyond the actual count exit at once — measured: launching
         // exactly the occupied 360 instead changes nothing)
@@ -1829,19 +1870,19 @@ void stage_scan_match_enqueue(const Slots& sl, const lvi_imu_hint* imu, void* d_
         // iteration 0 and the two after it search nearly everything (the first corrections move a feature 20 m out by half a metre):
         // 64 features per workgroup, many workgroups; later iterations mostly skip their searches: 256 features per workgroup
         if (it == 0) {
-            const dim3 rg((div_up(d.ext_cap, 64) + 7) & ~7, 1, S);
+            const dim3 rg((div_up(ext_cap_l, 64) + 7) & ~7, 1, S);
             if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 8, 8>), rg, dim3(512), 0, cx.stream, B, it));
             else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 2, 4>), rg, dim3(128), 0, cx.stream, B, it));
             else if (a.lds_tiles) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 4, 4, true>), rg, dim3(256), 0, cx.stream, B, it));
             else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, true, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
         } else if (it < d.icp_wide_from) {
-            const dim3 rg((div_up(d.ext_cap, 64) + 7) & ~7, 1, S);
+            const dim3 rg((div_up(ext_cap_l, 64) + 7) & ~7, 1, S);
             if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 8, 4>), rg, dim3(512), 0, cx.stream, B, it));
             else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 2, 4>), rg, dim3(128), 0, cx.stream, B, it));
             else if (a.lds_tiles) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 4, 4, true>), rg, dim3(256), 0, cx.stream, B, it));
             else LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<64, false, 4, 4>), rg, dim3(256), 0, cx.stream, B, it));
         } else {
-            const dim3 rg((div_up(d.ext_cap, 256) + 7) & ~7, 1, S);
+            const dim3 rg((div_up(ext_cap_l, 256) + 7) & ~7, 1, S);
             if (G1 == 8) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 8, 4>), rg, dim3(256), 0, cx.stream, B, it));
             else if (G1 == 2) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 2, 4>), rg, dim3(256), 0, cx.stream, B, it));
             else if (a.lds_tiles) LVI_LAUNCH(cx, "icp_gn", 128.0 * Q, hipLaunchKernelGGL((icp_gn_kernel<256, false, 4, 4, true>), rg, dim3(256), 0, cx.stream, B, it));

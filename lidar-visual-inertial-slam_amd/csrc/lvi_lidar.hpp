@@ -124,6 +124,8 @@ struct LidarDev {
     bool knn_bound = true;                                 // LVI_KNN_NO_BOUND=1 at create: every iteration searches the whole unit ball (tests: same bits)
     int nblk_icp = 0;
     IcpState* h_icp = nullptr;                             // pinned host mirror
+    int* h_gn_feat = nullptr;                              // pinned: features (corner + surf) of the last finished scan match of this slot, written by icp_final
+                                                           // (a HINT for the next GN launches' grid: read without synchronising, any value is correct)
     float* d_pose_init = nullptr;                          // [6] initial guess of the next scan match (device)
     // captured launch sequence of the whole per-scan path (lvi_scan_replay_enqueue)
     hipGraphExec_t graphExec = nullptr;

@@ -926,8 +926,12 @@ def test_knn_radius_bound_gives_identical_bits(pkg, hip, scene, monkeypatch):
     # features per workgroup (LVI_ICP_WIDE_FROM), with 2, 4 or 8 lanes per feature
     modes = (dict(LVI_KNN_NO_BOUND="1"), dict(LVI_KNN_NO_SKIP="1"), dict(), dict(LVI_KNN_SLACK="0"), dict(LVI_KNN_SLACK="0.2"), dict(LVI_ICP_G1="2"),
              dict(LVI_KNN_TILES="1"), dict(LVI_KNN_TILES="1", LVI_KNN_NO_BOUND="1"), dict(LVI_ICP_WIDE_FROM="1"), dict(LVI_ICP_WIDE_FROM="99", LVI_ICP_G0="8"),
-             dict(LVI_ICP_G0="2", LVI_ICP_G1="8"))
-    ALL = ("LVI_KNN_NO_BOUND", "LVI_KNN_NO_SKIP", "LVI_KNN_SLACK", "LVI_ICP_G1", "LVI_ICP_G0", "LVI_KNN_TILES", "LVI_ICP_WIDE_FROM")
+             dict(LVI_ICP_G0="2", LVI_ICP_G1="8"),
+             # … and whatever the launch grid: sized for the capacity, or for far fewer features than the scan has (every workgroup then
+             # walks on through several blocks of features), with 64 and with 256 features per block
+             dict(LVI_GN_GRID="cap"), dict(LVI_GN_GRID_FEATURES="300"), dict(LVI_GN_GRID_FEATURES="1100", LVI_ICP_WIDE_FROM="1"))
+    ALL = ("LVI_KNN_NO_BOUND", "LVI_KNN_NO_SKIP", "LVI_KNN_SLACK", "LVI_ICP_G1", "LVI_ICP_G0", "LVI_KNN_TILES", "LVI_ICP_WIDE_FROM", "LVI_GN_GRID",
+           "LVI_GN_GRID_FEATURES")
     for env in modes:
         for k in ALL:
             monkeypatch.delenv(k, raising=False)
