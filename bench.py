@@ -360,8 +360,13 @@ def main():
         base = s["name"].split("/")[0] + "_kernel"
         # keyed "kernel [grid G, wg W]" (separate rocprofv3 --pmc passes of this same command, tools/summarize_prof.py pmc);
         # the profiled tags with bytes are the largest geometry of their kernel
-        cand = [v["hbm_bytes_per_launch"] for k, v in traffic_tab.items() if k.startswith(base + " ")]
-        tr = max(cand) if cand else None
+        bases = [base] + (["vb_scatter_det_kernel"] if s["name"] == "vb_scatter/map" else [])      # (the map's partition is the deterministic form)
+        cand = [(v["hbm_bytes_per_launch"], v.get("launches_per_step", 1.0)) for k, v in traffic_tab.items() if any(k.startswith(b + " ") for b in bases)]
+        if s["name"].endswith("/map") and cand:
+            cand = [max(cand)]                           # the map's geometry is the largest of the kernel's (ring / scan grids share the kernel)
+        # the PMC passes run ONE scan per launch: a launch of this pass carries NB scans.  Several geometries of one kernel (icp_gn: the
+        # 64- and the 256-feature form) are weighted by their launches per step
+        tr = NB * sum(b * w for b, w in cand) / sum(w for _, w in cand) if cand else None
         ld = load_by_name.get(s["name"])
         under_load = None
         if ld and ld["launches"]:
@@ -372,7 +377,7 @@ def main():
         return dict(bound="hbm", kernel=s["name"], achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                     under_load=under_load,
                     measured_copy_gbs=copy_gbs, frac_of_measured_copy=(round(gbs / copy_gbs, 4) if copy_gbs else None),
-                    traffic=tr, traffic_source=(traffic_src if tr is not None else "no PMC pass of this round's build committed yet: null, not a stale figure"),
+                    traffic=(round(tr) if tr is not None else None), traffic_over_algorithmic=(round(tr / b, 2) if tr else None), traffic_source=(traffic_src if tr is not None else "no PMC pass of this round's build committed yet: null, not a stale figure"),
                     bytes_alg_per_launch=b, scans_per_launch=NB, avg_launch_us=round(s["avg_us"], 2),
                     launches_per_step=s["launches"] / max(args.profile_steps, 1), note=note)
 
