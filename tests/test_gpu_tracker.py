@@ -28,13 +28,25 @@ def pair(pkg, oracle, hip):
     o.close(); g.close()
 
 
-def test_pyramid_bit_exact(pkg, pair, frames):
+def test_pyramid_bit_exact(pkg, pair, frames, oracle, hip):
     A = pkg._abi
     o, g = pair
     for t in (o, g):
         t.push_image(frames["img0"])
     for what in (A.TDBG_PYRAMID_L1, A.TDBG_PYRAMID_L2, A.TDBG_PYRAMID_L3):
         np.testing.assert_array_equal(o.debug_get(what, np.uint8), g.debug_get(what, np.uint8))
+    # odd sizes at every level, sizes that end inside a workgroup's tile
+    rng = np.random.default_rng(77)
+    for (h, w) in ((239, 317), (241, 323), (185, 263)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        res = []
+        for lib in (oracle, hip):
+            t = pkg.TrackerHotpath(lib, max_width=w, max_height=h)
+            t.push_image(img)
+            res.append([t.debug_get(what, np.uint8).copy() for what in (A.TDBG_PYRAMID_L1, A.TDBG_PYRAMID_L2, A.TDBG_PYRAMID_L3)])
+            t.close()
+        for k in range(3):
+            np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=f"{w}x{h} level {k + 1}")
 
 
 def test_mineig_map_and_gftt_exact(pkg, pair, frames):
