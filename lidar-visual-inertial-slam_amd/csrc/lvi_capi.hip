@@ -63,6 +63,7 @@ struct lvi_lidar {
     std::vector<int32_t> vkeys, vcells, vcounts;    // debug of the last lvi_voxel_downsample
     bool vdbg_pending = false; int vdbg_n = 0;      // … not fetched yet (lvi_debug_get does it)
     bool have_icp_host = false;
+    bool icp_host_full = false;            // the IcpState mirror (traces for the debug views) has been fetched for the last match
     lvi_lidar* share_owner = nullptr;               // lvi_map_share: the handle whose raw map this one reads
     std::atomic<int> shared_by{0};                  // handles that read this one's raw map (they may live on other host threads): it must not change while > 0
     std::vector<lvi_lidar*> sharers;                // … who they are (g_share_mu): an owner that is destroyed first sends them back to their own memory
@@ -239,6 +240,7 @@ static void release_slot(LidarDev& d)
     d.arena.release();
     if (d.h_icp) (void)hipHostFree(d.h_icp);
     if (d.h_gn_feat) (void)hipHostFree(d.h_gn_feat);
+    if (d.h_res) (void)hipHostFree(d.h_res);
     if (d.h_kfSeg) (void)hipHostFree(d.h_kfSeg);
     if (d.inc.h_pieces) (void)hipHostFree(d.inc.h_pieces);
     if (d.inc.h_status) (void)hipHostFree(d.inc.h_status);
@@ -479,15 +481,15 @@ int32_t lvi_scan_match(lvi_lidar* h, const lvi_imu_hint* imu, float pose[6], lvi
         for (int it0 = 0;; it0 += chunk) {
             const int it1 = std::min(it0 + chunk, max_it);
             stage_scan_match_enqueue(d, imu, nullptr, it0, it1);
-            d2h(d, d.h_icp, d.icp, 1);
-            d2h(d, nq, d.voxScan.d_nout, 3);
-            d2h(d, dw, d.d_status, 2);                                // the device status words ride along: one wait per chunk
-            sync(d);
-            if (it1 >= max_it || d.h_icp->done || d.h_icp->status != LVI_OK || (dw[0] | dw[1])) break;
+            sync(d);                                                  // the finish step wrote the result block (counts and device status words
+            const IcpHostResult& r = *d.h_res;                        // ride along) into pinned host memory: one wait per chunk, no copies
+            for (int k = 0; k < 3; k++) nq[k] = r.nq[k];
+            dw[0] = r.dw[0]; dw[1] = r.dw[1];
+            if (it1 >= max_it || r.done || r.status != LVI_OK || (dw[0] | dw[1])) break;
         }
-        h->have_icp_host = true;
+        h->have_icp_host = true; h->icp_host_full = false;
         int32_t st = dev_status_code(dw[0] | dw[1]); if (st) return st;
-        const IcpState& s = *d.h_icp;
+        const IcpHostResult& s = *d.h_res;
         memset(out, 0, sizeof(*out));
         out->status = s.final_status; out->iters = s.iters; out->converged = s.converged;
         out->degenerate = s.degenerate; out->n_corner_ds = nq[0]; out->n_surf_ds = nq[1];
@@ -988,11 +990,13 @@ int32_t lvi_debug_get(lvi_lidar* h, int32_t what, void* dst, int64_t cap, int64_
                 return dbg_out(what == LVI_DBG_VOXEL_KEYS ? h->vkeys : (what == LVI_DBG_VOXEL_CELLS ? h->vcells : h->vcounts), 0, dst, cap, n_bytes);
             case LVI_DBG_ICP_JTJ: {
                 if (!h->have_icp_host) return fail(LVI_ERR_STATE, "scan_match not run");
+                if (!h->icp_host_full) { d2h(d, d.h_icp, d.icp, 1); sync(d); h->icp_host_full = true; }
                 std::vector<float> v(d.h_icp->jtj, d.h_icp->jtj + 27 * d.h_icp->iters);
                 return dbg_out(v, 0, dst, cap, n_bytes);
             }
             case LVI_DBG_ICP_POSE_TRACE: {
                 if (!h->have_icp_host) return fail(LVI_ERR_STATE, "scan_match not run");
+                if (!h->icp_host_full) { d2h(d, d.h_icp, d.icp, 1); sync(d); h->icp_host_full = true; }
                 const int rows = d.h_icp->status == LVI_OK || d.h_icp->status == LVI_TOO_FEW_CORRESPONDENCES ? d.h_icp->iters + 1 : 0;
                 std::vector<float> v(d.h_icp->pose_trace, d.h_icp->pose_trace + 6 * rows);
                 return dbg_out(v, 0, dst, cap, n_bytes);

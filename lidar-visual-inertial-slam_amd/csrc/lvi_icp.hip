@@ -631,6 +631,7 @@ struct IcpArgs {
     unsigned char* fit_ok;                        // [cap] 0: no fit stored; 1: stored, geometric gate passed; 2: stored, gate failed
     float knn_slack;                              // metres added to the radius of a bounded search (room for later iterations to skip theirs)
     int lds_tiles;                                // LVI_KNN_TILES=1: phase A stages the index tile of a wavefront's features in LDS when it fits (4 lanes per feature; same bits; see DESIGN for why it is not the default)
+    IcpHostResult* h_res; const int* nout3;       // pinned host block the finish step fills (lvi_scan_match reads it after one wait); voxScan.d_nout
     int* h_feat;                                  // pinned host word: this match's feature count, for the next launches' grid (LidarDev::h_gn_feat)
     int stamp_iter;                               // the iteration whose phase stamps are kept in cyc[] (LVI_ICP_STAMP_ITER, default: the last one launched)
     int xcd_map;                                  // residual workgroups are dealt to the XCDs in contiguous feature ranges (LVI_ICP_NO_XCD_MAP=1: in launch order)
@@ -1516,7 +1517,18 @@ __global__ __launch_bounds__(64) void icp_final_kernel(Batch<IcpArgs> B_, int n_
         (void)icp_iter_end(a, n_iters - 1, ssum, threadIdx.x, true, s.degenerate, P);
     }
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    if (threadIdx.x == 0) { icp_finish_body(a); if (a.h_feat) *a.h_feat = a.nq[0] + a.nq[1]; }
+    if (threadIdx.x == 0) {
+        icp_finish_body(a);
+        if (a.h_feat) *a.h_feat = a.nq[0] + a.nq[1];
+        if (a.h_res) {
+            IcpHostResult& r = *a.h_res;
+            r.final_status = s.final_status; r.iters = s.iters; r.converged = s.converged; r.degenerate = s.degenerate; r.done = s.done; r.status = s.status;
+            for (int k = 0; k < LVI_ICP_MAX_ITERS; k++) r.n_sel[k] = s.n_sel[k];
+            for (int k = 0; k < 6; k++) r.final_pose[k] = s.final_pose[k];
+            for (int k = 0; k < 3; k++) r.nq[k] = a.nout3[k];
+            r.dw[0] = a.d_status[0]; r.dw[1] = a.d_status[1];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void transform_kernel(const lvi_pt* in, int n, IcpPose pose, lvi_pt* out)
@@ -1578,7 +1590,7 @@ IcpArgs icp_args(LidarDev& d)
     a.cap = d.ext_cap; a.nn_pt = d.nnPt; a.fit = d.fitA; a.fit2 = d.fitB; a.fit_ok = d.fitOk; a.acc = d.icpAcc;
     a.nn_ref = (d.knn_bound && d.knn_skip) ? d.nnRef : nullptr; a.knn_slack = d.knn_slack;
     { static const bool no_map = getenv("LVI_ICP_NO_XCD_MAP") != nullptr; a.xcd_map = no_map ? 0 : 1; }
-    a.stamp_iter = d.icp_stamp_iter; a.lds_tiles = d.knn_tiles ? 1 : 0; a.h_feat = d.h_gn_feat;
+    a.stamp_iter = d.icp_stamp_iter; a.lds_tiles = d.knn_tiles ? 1 : 0; a.h_feat = d.h_gn_feat; a.h_res = d.h_res; a.nout3 = d.voxScan.d_nout;
     a.edgeMin = d.P.edgeFeatureMinValidNum; a.surfMin = d.P.surfFeatureMinValidNum;
     a.max_iters = std::min(d.P.icp_max_iters, LVI_ICP_MAX_ITERS); a.disable_break = d.P.icp_disable_break;
     a.rot_tol = d.P.rotation_tollerance; a.z_tol = d.P.z_tollerance; a.imu_weight = (double)d.P.imuRPYWeight;

@@ -37,6 +37,16 @@ struct IcpState {                        // device, one per handle
     float final_pose[6];
 };
 
+// what lvi_scan_match returns, written by the finish step into pinned host memory (no copy commands behind the loop: a 3 KB
+// hipMemcpyAsync of the whole IcpState and two more for the counts and status words were three blit kernels per chunk)
+struct IcpHostResult {
+    int final_status, iters, converged, degenerate, done, status;
+    int n_sel[LVI_ICP_MAX_ITERS];
+    float final_pose[6];
+    int nq[3];                           // voxScan.d_nout: corner_ds, surf_ds, total
+    int dw[2];                           // device status words (scan side, map build)
+};
+
 struct GridIndex {                       // uniform 0.5 m grid over one DS map (a-6 replacement for the kd-tree)
     int* cell_start = nullptr;           // [max_cells + 2]
     int* count = nullptr;                // [max_cells + 2] points per cell (zero between builds)
@@ -124,6 +134,7 @@ struct LidarDev {
     bool knn_bound = true;                                 // LVI_KNN_NO_BOUND=1 at create: every iteration searches the whole unit ball (tests: same bits)
     int nblk_icp = 0;
     IcpState* h_icp = nullptr;                             // pinned host mirror
+    IcpHostResult* h_res = nullptr;                        // pinned: the finish step's result block
     int* h_gn_feat = nullptr;                              // pinned: features (corner + surf) of the last finished scan match of this slot, written by icp_final
                                                            // (a HINT for the next GN launches' grid: read without synchronising, any value is correct)
     float* d_pose_init = nullptr;                          // [6] initial guess of the next scan match (device)

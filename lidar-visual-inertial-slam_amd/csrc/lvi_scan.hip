@@ -1032,6 +1032,8 @@ void lidar_allocate(LidarDev& d)
     LVI_HIP(hipMemcpyAsync(d.d_fresh, &one, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
     LVI_HIP(hipMemcpyAsync(d.d_dk_first, &int_max, sizeof(int), hipMemcpyHostToDevice, d.ctx.stream));
     LVI_HIP(hipHostMalloc((void**)&d.h_icp, sizeof(IcpState), hipHostMallocDefault));
+    LVI_HIP(hipHostMalloc((void**)&d.h_res, sizeof(IcpHostResult), hipHostMallocDefault));
+    memset(d.h_res, 0, sizeof(IcpHostResult));
     LVI_HIP(hipHostMalloc((void**)&d.h_gn_feat, 64, hipHostMallocDefault));
     *d.h_gn_feat = 0;
     for (int s = 0; s < 2; s++) {
