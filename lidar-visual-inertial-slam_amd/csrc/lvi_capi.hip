@@ -62,6 +62,8 @@ struct lvi_lidar {
     LidarDev& cur() { return *slots[sel]; }
     std::vector<int32_t> vkeys, vcells, vcounts;    // debug of the last lvi_voxel_downsample
     bool vdbg_pending = false; int vdbg_n = 0;      // … not fetched yet (lvi_debug_get does it)
+    // lvi_voxel_downsample of a small cloud (<= VOX_TINY points: the node's key-pose grid): pinned staging of the one-launch form
+    lvi_pt *vt_in = nullptr, *vt_out = nullptr; int *vt_hdr = nullptr, *vt_cells = nullptr, *vt_counts = nullptr, *vt_keys = nullptr;
     bool have_icp_host = false;
     bool icp_host_full = false;            // the IcpState mirror (traces for the debug views) has been fetched for the last match
     lvi_lidar* share_owner = nullptr;               // lvi_map_share: the handle whose raw map this one reads
@@ -274,6 +276,7 @@ void lvi_lidar_destroy(lvi_lidar* h)
     d.prof.collect();
     for (auto& q : h->more) release_slot(*q);
     release_slot(d);
+    if (h->vt_in) { (void)hipHostFree(h->vt_in); (void)hipHostFree(h->vt_out); (void)hipHostFree(h->vt_hdr); (void)hipHostFree(h->vt_cells); (void)hipHostFree(h->vt_counts); (void)hipHostFree(h->vt_keys); }
     if (d.ctx.stream) (void)hipStreamDestroy(d.ctx.stream);
     if (d.ctx2.stream) (void)hipStreamDestroy(d.ctx2.stream);
     for (int s = 0; s < LVI_LIDAR_MARKS; s++) if (d.evMark[s]) (void)hipEventDestroy(d.evMark[s]);
@@ -876,6 +879,31 @@ int32_t lvi_voxel_downsample(lvi_lidar* h, const lvi_pt* in, int32_t n, float le
 {
     if (!h || n < 0 || (n > 0 && !in) || !(leaf > 0.f) || !n_out) return fail(LVI_ERR_INVALID_ARG, "bad voxel arguments");
     if (n > h->d.voxGen.seg_cap) return fail(LVI_ERR_CAPACITY, "n exceeds capacity");
+    const bool no_tiny = getenv("LVI_VOX_NO_TINY") != nullptr;                // tests: the general path for every size
+    if (n > 0 && n <= VOX_TINY && !no_tiny) return guarded(h, [&]() -> int32_t {
+        LidarDev& d = h->d;
+        if (!h->vt_in) {
+            LVI_HIP(hipHostMalloc((void**)&h->vt_in, sizeof(lvi_pt) * VOX_TINY, hipHostMallocDefault));
+            LVI_HIP(hipHostMalloc((void**)&h->vt_out, sizeof(lvi_pt) * VOX_TINY, hipHostMallocDefault));
+            LVI_HIP(hipHostMalloc((void**)&h->vt_hdr, 64, hipHostMallocDefault));
+            LVI_HIP(hipHostMalloc((void**)&h->vt_cells, sizeof(int) * VOX_TINY, hipHostMallocDefault));
+            LVI_HIP(hipHostMalloc((void**)&h->vt_counts, sizeof(int) * VOX_TINY, hipHostMallocDefault));
+            LVI_HIP(hipHostMalloc((void**)&h->vt_keys, sizeof(int) * VOX_TINY, hipHostMallocDefault));
+        }
+        sync(d);                                                            // (the staging block is single: nothing of an earlier call may still read it)
+        std::memcpy(h->vt_in, in, sizeof(lvi_pt) * (size_t)n);
+        voxel_tiny(d.ctx, h->vt_in, n, leaf, d.voxGen.seg_cap, d.voxGen.bin_pts, d.voxGen.bin_max, h->vt_out, h->vt_hdr, h->vt_cells, h->vt_counts, h->vt_keys);
+        sync(d);
+        const int m = h->vt_hdr[0];
+        *n_out = m;
+        const int fetch = std::min(m, out_capacity);
+        if (fetch > 0) std::memcpy(out, h->vt_out, sizeof(lvi_pt) * (size_t)fetch);
+        h->vdbg_pending = false;
+        if (h->vt_hdr[1]) { h->vkeys.clear(); h->vcells.clear(); h->vcounts.clear(); }      // overflow rule: no voxels to show (as the general path's views)
+        else { h->vkeys.assign(h->vt_keys, h->vt_keys + n); h->vcells.assign(h->vt_cells, h->vt_cells + m); h->vcounts.assign(h->vt_counts, h->vt_counts + m); }
+        if (m > out_capacity) return fail(LVI_ERR_CAPACITY, "voxel output capacity too small");
+        return LVI_OK;
+    });
     return guarded(h, [&]() -> int32_t {
         LidarDev& d = h->d;
         h2d(d, d.genIn, in, (size_t)n);

@@ -1213,6 +1213,88 @@ __global__ __launch_bounds__(256) void vb_copy_kernel(Batch<VoxArgs> B_)
     }
 }
 
+
+// =====================================================================================================
+// A cloud of at most VOX_TINY points (the node's key-pose grid: a few dozen to a few hundred poses per scan, mapOptimization.cpp:
+// 894-929) in ONE workgroup and one launch: bounding box, grid geometry (vox_setup_math), keys, order by (key, input index) by
+// counting, heads, fixed-point centroids — the general path's expressions, hence its bits — read from and written to pinned host
+// memory.  The general path is nine launches, an upload and two reads for the same cloud: ~100 us of latency per sequential scan.
+// =====================================================================================================
+struct VoxTinyArgs {
+    const lvi_pt* in; int n; float leaf; int seg_cap, bin_pts, bin_max;
+    lvi_pt* out; int* hdr;                            // hdr: {voxels, overflow}
+    int* cells; int* counts; int* keys;               // the debug views' voxel idx / points per voxel / voxel idx per input point
+};
+__global__ __launch_bounds__(VOX_TINY) void vox_tiny_kernel(VoxTinyArgs a)
+{
+    __shared__ lvi_pt spt[VOX_TINY];
+    __shared__ unsigned long long sk[VOX_TINY], ssorted[VOX_TINY];
+    __shared__ VoxGrid sg;
+    __shared__ float smn[VOX_TINY / 64][4], smx[VOX_TINY / 64][4];
+    __shared__ int ws[VOX_TINY / 64 + 1];
+    const int i = threadIdx.x, n = a.n;
+    const bool in_range = i < n;
+    lvi_pt p = {0.f, 0.f, 0.f, 0.f};
+    if (in_range) p = a.in[i];
+    spt[i] = p;
+    float lo[4] = {in_range ? p.x : INFINITY, in_range ? p.y : INFINITY, in_range ? p.z : INFINITY, in_range ? p.intensity : INFINITY};
+    float hi[4] = {in_range ? p.x : -INFINITY, in_range ? p.y : -INFINITY, in_range ? p.z : -INFINITY, in_range ? p.intensity : -INFINITY};
+#pragma unroll
+    for (int d = 0; d < 4; d++) { lo[d] = wave_min(lo[d]); hi[d] = wave_max(hi[d]); }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) { smn[wave_id()][d] = lo[d]; smx[wave_id()][d] = hi[d]; }
+    }
+    __syncthreads();
+    if (i == 0) {
+        float l4[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, h4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int w = 0; w < VOX_TINY / 64; w++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) { l4[d] = fminf(l4[d], smn[w][d]); h4[d] = fmaxf(h4[d], smx[w][d]); }
+        sg.n_valid = n;
+        if (n > 0) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) { sg.bb[d] = f2ord(l4[d]); sg.bb[3 + d] = f2ord(h4[d]); }
+        } else {
+            sg.bb[0] = sg.bb[1] = sg.bb[2] = 0xFFFFFFFFu; sg.bb[3] = sg.bb[4] = sg.bb[5] = 0u;
+            l4[3] = h4[3] = 0.f;
+        }
+        vox_setup_math(sg, a.leaf, a.seg_cap, l4[3], h4[3], a.bin_pts, a.bin_max);
+    }
+    __syncthreads();
+    if (sg.overflow || n == 0) {                     // PCL's overflow rule: output = input, in input order
+        if (in_range) a.out[i] = p;
+        if (i == 0) { a.hdr[0] = n; a.hdr[1] = n > 0 ? 1 : 0; }
+        return;
+    }
+    const unsigned key = in_range ? vox_key_of_pt(sg, p) : 0xFFFFFFFFu;
+    const unsigned long long mine = in_range ? (((unsigned long long)key << 32) | (unsigned)i) : ~0ull;
+    sk[i] = mine;
+    if (in_range) a.keys[i] = (int)key;
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < n; j++) rank += sk[j] < mine ? 1 : 0;          // every lane reads the same word: a broadcast
+    if (in_range) ssorted[rank] = mine;                                // keys are unique (input index in the low word)
+    __syncthreads();
+    const unsigned k = in_range ? (unsigned)(ssorted[i] >> 32) : 0u;
+    const bool head = in_range && (i == 0 || (unsigned)(ssorted[i - 1] >> 32) != k);
+    int nvox;
+    const int v = block_excl_scan<VOX_TINY>(head ? 1 : 0, ws, &nvox);
+    if (head) {
+        const VoxFx f = vox_fx_of(sg);
+        unsigned long long sx = 0ull, sy = 0ull, sz = 0ull, si = 0ull;
+        unsigned cnt = 0u;
+        for (int q = i; q < n && (unsigned)(ssorted[q] >> 32) == k; q++) {
+            unsigned long long t[4];
+            (void)vox_fx_point(f, spt[(unsigned)ssorted[q]], t);
+            sx += t[0]; sy += t[1]; sz += t[2]; si += t[3]; cnt++;
+        }
+        a.out[v] = fx_centroid(sg, k, sx, sy, sz, si, cnt);
+        a.cells[v] = (int)k; a.counts[v] = (int)cnt;
+    }
+    if (i == 0) { a.hdr[0] = nvox; a.hdr[1] = 0; }
+}
+
 }  // namespace
 
 static VoxArgs make_args(const VoxelPlan& p)
@@ -1502,6 +1584,13 @@ void incmap_emit(const Ctx& ctx, const IncMap& m, int n_active, const float leaf
 
 // What depends on the plan's INPUT alone and is produced where the input is written (upload / assembly) instead of once per
 // re-voxelisation: the bbox partial records and — the grid geometry following from the bbox — the points per bin.
+void voxel_tiny(const Ctx& ctx, const lvi_pt* in_pinned, int n, float leaf, int seg_cap, int bin_pts, int bin_max, lvi_pt* out_pinned, int* hdr_pinned,
+                int* cells_pinned, int* counts_pinned, int* keys_pinned)
+{
+    VoxTinyArgs a{in_pinned, n, leaf, seg_cap, bin_pts, bin_max, out_pinned, hdr_pinned, cells_pinned, counts_pinned, keys_pinned};
+    LVI_LAUNCH(ctx, "vox_tiny", 32.0 * n, hipLaunchKernelGGL(vox_tiny_kernel, dim3(1), dim3(VOX_TINY), 0, ctx.stream, a));
+}
+
 void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& p, const char* tag, double n_hint)
 {
     Batch<VoxArgs> B;

@@ -203,5 +203,9 @@ void voxel_downsample_batch(const Ctx& ctx, const VoxelPlan* const* plans, int S
 void voxel_bbox_pass(const Ctx& ctx, const VoxelPlan& plan, const char* tag, double n_hint);
 // the realisation the next voxel_downsample_batch of this plan will enqueue (AUTO resolved from the previous batch's hint)
 int voxel_resolve_mode(const VoxelPlan& plan);
+// a cloud of at most VOX_TINY points, one workgroup, one launch, pinned host memory in and out (the node's key-pose grid)
+constexpr int VOX_TINY = 1024;
+void voxel_tiny(const Ctx& ctx, const lvi_pt* in_pinned, int n, float leaf, int seg_cap, int bin_pts, int bin_max, lvi_pt* out_pinned, int* hdr_pinned,
+                int* cells_pinned, int* counts_pinned, int* keys_pinned);
 
 }  // namespace lvi

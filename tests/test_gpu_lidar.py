@@ -270,6 +270,42 @@ def test_voxel_modes_give_identical_bits(pkg, hip):
     a.close(); b.close()
 
 
+def test_voxel_small_cloud_form_gives_the_general_path_bits(pkg, hip, monkeypatch):
+    """round 3: a cloud of at most 1 024 points (the node's key-pose grid, mapOptimization.cpp:894-929) is filtered by ONE workgroup in one
+    launch; same output bits, voxel idx and counts as the nine-launch general path (LVI_VOX_NO_TINY=1), incl. the overflow rule, one
+    point, all points in one voxel, and key-pose-like input (a trajectory with a 2 m leaf)"""
+    A = pkg._abi
+    kw = dict(N_SCAN=4, Horizon_SCAN=1000, max_raw_points=4096, max_map_points=20000)
+    rng = np.random.default_rng(33)
+    cases = []
+    for n in (1, 2, 5, 64, 65, 300, 777, 1024):
+        pts = np.zeros((n, 4), np.float32)
+        pts[:, :3] = rng.uniform(-25, 25, (n, 3)) * [1, 1, 0.2]; pts[:, 3] = rng.uniform(0, 255, n)
+        for leaf in (0.4, 2.0, 0.02, 30.0):
+            cases.append((pts, leaf))
+    t = np.linspace(0, 60, 400, dtype=np.float32)
+    cases.append((np.stack([t, np.sin(0.2 * t) * 8, 0.02 * t, np.arange(400, dtype=np.float32)], axis=1).astype(np.float32), 2.0))   # key poses, intensity = index
+    cases.append((np.repeat(np.array([[1.5, -2.5, 0.25, 7.0]], np.float32), 1024, axis=0), 0.4))
+    cases.append((np.array([[0, 0, 0, 1], [3000, 3000, 3000, 2], [1, 1, 1, 3]], np.float32), 0.01))                                   # overflow rule
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("LVI_VOX_NO_TINY", env)
+        else:
+            monkeypatch.delenv("LVI_VOX_NO_TINY", raising=False)
+        g = pkg.LidarHotpath(hip, **kw)
+        rows = []
+        for pts, leaf in cases:
+            v = xyzi(g.voxel_downsample(pts, leaf)).view(np.uint32).copy()
+            rows.append((v, g.debug_get(A.DBG_VOXEL_CELLS, np.int32).copy(), g.debug_get(A.DBG_VOXEL_COUNTS, np.int32).copy(), g.debug_get(A.DBG_VOXEL_KEYS, np.int32).copy()))
+        out.append(rows)
+        g.close()
+    monkeypatch.delenv("LVI_VOX_NO_TINY", raising=False)
+    for (a, b), (pts, leaf) in zip(zip(*out), cases):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y, err_msg=f"n={len(pts)} leaf={leaf}")
+
+
 def test_voxel_downsample_edge_cases(pkg, pair):
     o, g = pair
     assert len(g.voxel_downsample(np.zeros((0, 4), np.float32), 0.4)) == 0
