@@ -890,10 +890,13 @@ int32_t lvi_voxel_downsample(lvi_lidar* h, const lvi_pt* in, int32_t n, float le
             LVI_HIP(hipHostMalloc((void**)&h->vt_counts, sizeof(int) * VOX_TINY, hipHostMallocDefault));
             LVI_HIP(hipHostMalloc((void**)&h->vt_keys, sizeof(int) * VOX_TINY, hipHostMallocDefault));
         }
-        sync(d);                                                            // (the staging block is single: nothing of an earlier call may still read it)
+        // On the handle's SECOND stream: the call returns its result, so it orders with nothing else — and the node calls it (key-pose grid,
+        // extractNearby) right after it enqueued the scan's voxel grids on the main stream: there the wait below would be a wait for all of
+        // them, and the local-map update that follows would start when the scan-side stages are over instead of beside them.
+        // (The staging block is single; the previous call waited for its kernel.)
         std::memcpy(h->vt_in, in, sizeof(lvi_pt) * (size_t)n);
-        voxel_tiny(d.ctx, h->vt_in, n, leaf, d.voxGen.seg_cap, d.voxGen.bin_pts, d.voxGen.bin_max, h->vt_out, h->vt_hdr, h->vt_cells, h->vt_counts, h->vt_keys);
-        sync(d);
+        voxel_tiny(d.ctx2, h->vt_in, n, leaf, d.voxGen.seg_cap, d.voxGen.bin_pts, d.voxGen.bin_max, h->vt_out, h->vt_hdr, h->vt_cells, h->vt_counts, h->vt_keys);
+        LVI_HIP(hipStreamSynchronize(d.ctx2.stream));
         const int m = h->vt_hdr[0];
         *n_out = m;
         const int fetch = std::min(m, out_capacity);
