@@ -1517,16 +1517,21 @@ __global__ __launch_bounds__(64) void icp_final_kernel(Batch<IcpArgs> B_, int n_
         (void)icp_iter_end(a, n_iters - 1, ssum, threadIdx.x, true, s.degenerate, P);
     }
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    if (threadIdx.x == 0) {
-        icp_finish_body(a);
-        if (a.h_feat) *a.h_feat = a.nq[0] + a.nq[1];
-        if (a.h_res) {
-            IcpHostResult& r = *a.h_res;
-            r.final_status = s.final_status; r.iters = s.iters; r.converged = s.converged; r.degenerate = s.degenerate; r.done = s.done; r.status = s.status;
-            for (int k = 0; k < LVI_ICP_MAX_ITERS; k++) r.n_sel[k] = s.n_sel[k];
-            for (int k = 0; k < 6; k++) r.final_pose[k] = s.final_pose[k];
-            for (int k = 0; k < 3; k++) r.nq[k] = a.nout3[k];
-            r.dw[0] = a.d_status[0]; r.dw[1] = a.d_status[1];
+    if (threadIdx.x == 0) { icp_finish_body(a); if (a.h_feat) *a.h_feat = a.nq[0] + a.nq[1]; }
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    if (a.h_res) {
+        // the result block goes out a word per lane and round (81 posted writes over PCIe from ONE lane were 7 us of this launch)
+        static_assert(sizeof(IcpHostResult) % 4 == 0, "words");
+        constexpr int NW = (int)(sizeof(IcpHostResult) / 4), M = LVI_ICP_MAX_ITERS;
+        for (int w = threadIdx.x; w < NW; w += 64) {
+            int v = 0;
+            if (w == 0) v = s.final_status; else if (w == 1) v = s.iters; else if (w == 2) v = s.converged; else if (w == 3) v = s.degenerate;
+            else if (w == 4) v = s.done; else if (w == 5) v = s.status;
+            else if (w < 6 + M) v = s.n_sel[w - 6];
+            else if (w < 12 + M) v = __float_as_int(s.final_pose[w - 6 - M]);
+            else if (w < 15 + M) v = a.nout3[w - 12 - M];
+            else if (w < 17 + M) v = a.d_status[w - 15 - M];
+            reinterpret_cast<int*>(a.h_res)[w] = v;
         }
     }
 }
