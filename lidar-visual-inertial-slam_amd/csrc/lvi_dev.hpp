@@ -193,6 +193,27 @@ __device__ __forceinline__ int block_excl_scan(int v, int* ws, int* total)
     return r;
 }
 
+// the same for 64-bit words (several counters packed into one word are scanned together: one pass of barriers instead of one per counter)
+template <int BLOCK>
+__device__ __forceinline__ unsigned long long block_excl_scan_u64(unsigned long long v, unsigned long long* ws, unsigned long long* total)
+{
+    constexpr int NW = BLOCK / 64;
+    const unsigned long long incl = wave_incl_scan(v);
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned long long w = (threadIdx.x < NW) ? ws[threadIdx.x] : 0ull;
+        unsigned long long wi = wave_incl_scan(w);
+        if (threadIdx.x < NW) ws[threadIdx.x] = wi - w;
+        if (threadIdx.x == NW - 1) ws[NW] = wi;
+    }
+    __syncthreads();
+    const unsigned long long r = ws[wave_id()] + incl - v;
+    if (total) *total = ws[NW];
+    __syncthreads();
+    return r;
+}
+
 // order-preserving float <-> uint encoding for atomicMin/atomicMax on floats
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float ord2f(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }

@@ -793,10 +793,22 @@ __global__ __launch_bounds__(256) void vb_scan_kernel(Batch<VoxArgs> B_)
         lsum += (!wide && v[j] > 0 && v[j] <= VB_LIGHT) ? 1 : 0;
     }
     int tot, ctot, mtot, ltot;
-    int ex = block_excl_scan<256>(sum, ws, &tot);
-    int cex = block_excl_scan<256>(csum, ws, &ctot);
-    int mex = block_excl_scan<256>(msum, ws, &mtot);
-    int lex = block_excl_scan<256>(lsum, ws, &ltot);
+    int ex, cex, mex, lex;
+    // the four prefix sums in ONE scan of a packed word (points 24 bits, chunks 14, chunks of multi-chunk bins 13, light bins 13) when the
+    // plan's capacities fit the fields — every plan of the library does; four scans were twelve barriers of this one-workgroup kernel
+    if (a.seg_cap < (1 << 24) && a.max_chunks < (1 << 14) && a.max_multi < (1 << 13)) {
+        __shared__ unsigned long long ws64[8];
+        unsigned long long t64;
+        const unsigned long long e64 = block_excl_scan_u64<256>((unsigned long long)sum | ((unsigned long long)csum << 24) | ((unsigned long long)msum << 38) |
+                                                                    ((unsigned long long)lsum << 51), ws64, &t64);
+        ex = (int)(e64 & 0xFFFFFFull); cex = (int)((e64 >> 24) & 0x3FFFull); mex = (int)((e64 >> 38) & 0x1FFFull); lex = (int)(e64 >> 51);
+        tot = (int)(t64 & 0xFFFFFFull); ctot = (int)((t64 >> 24) & 0x3FFFull); mtot = (int)((t64 >> 38) & 0x1FFFull); ltot = (int)(t64 >> 51);
+    } else {
+        ex = block_excl_scan<256>(sum, ws, &tot);
+        cex = block_excl_scan<256>(csum, ws, &ctot);
+        mex = block_excl_scan<256>(msum, ws, &mtot);
+        lex = block_excl_scan<256>(lsum, ws, &ltot);
+    }
     int* cs = a.chunkStart + (size_t)s * (VB_NB + 1);
     int* ms = a.multiStart + (size_t)s * (VB_NB + 1);
     int* lb = a.lightBin + (size_t)s * (VB_NB + 1);
