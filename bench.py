@@ -106,12 +106,17 @@ def main():
     def dev_sync():
         if on_gpu:
             torch.cuda.synchronize()
-    if world > 1:
+    # LVI_BENCH_RCCL_WORLD1=1 (tests/test_gpu_rccl.py, a one-GPU box): the N > 1 control flow with a world of ONE rank over the nccl
+    # backend — every collective of this file (broadcast of the map, all_gather of the pose records per step, MAX all_reduce of the
+    # window time, the tracker-rate gather, the barriers) executes through RCCL, trivially; never set by the driver
+    use_dist = world > 1 or (os.environ.get("LVI_BENCH_RCCL_WORLD1") == "1" and on_gpu)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if rehearse or not on_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)          # RCCL
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)          # RCCL
     pkg = graft.import_package()
     A, S, R = pkg._abi, pkg.synth, pkg.replay
     hip = pkg.load_hip()                      # raises when the HIP library is missing: no fallback
@@ -133,7 +138,7 @@ def main():
     if rank == 0:
         mc, ms = S.make_map(g, args.keyframes, args.kf_n_raw, seed=4711, torch_device=dev, target_surf=args.map_points)
         hdr[0], hdr[1] = len(mc), len(ms)
-    if world > 1:
+    if use_dist:
         dist.broadcast(hdr, 0)
     nc, ns = int(hdr[0]), int(hdr[1])
     d_mc = torch.empty((nc, 4), dtype=torch.float32, device=dev)
@@ -141,7 +146,7 @@ def main():
     if rank == 0:
         d_mc.copy_(torch.from_numpy(A.pts_xyzi(mc)))
         d_ms.copy_(torch.from_numpy(A.pts_xyzi(ms)))
-    if world > 1:
+    if use_dist:
         dist.broadcast(d_mc, 0)
         dist.broadcast(d_ms, 0)
     dev_sync()
@@ -232,14 +237,14 @@ def main():
         enq[0] += time.perf_counter() - t_e
 
     def gather(j):
-        if world > 1:
-            R.gather_records(d_rec[j * per_step:(j + 1) * per_step], world, dist)   # RCCL all_gather: 32 B pose record per scan
+        if use_dist:
+            R.gather_records(d_rec[j * per_step:(j + 1) * per_step], world, dist, force=True)   # RCCL all_gather: 32 B pose record per scan
 
     roll = R.RollingReplay(hs, issue, gather, depth=args.queue_depth)
 
     def fence():
         dev_sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         dev_sync()
 
@@ -264,7 +269,7 @@ def main():
         roll.flush()
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax[0])
@@ -300,7 +305,7 @@ def main():
             tracker_out = bench_tracker(pkg, hip, dev_index, rank, world, args.tracker_seconds)
         except Exception as e:                      # noqa: BLE001 — the tracker leg must not hide the headline
             tracker_out = dict(error=str(e), value=0.0)
-        if world > 1:                               # outside the try: every rank issues this collective, whatever its leg did
+        if use_dist:                                # outside the try: every rank issues this collective, whatever its leg did
             tr = torch.tensor([float(tracker_out.get("value", 0.0))], dtype=torch.float64, device=dev)
             allr = [torch.zeros_like(tr) for _ in range(world)]
             dist.all_gather(allr, tr)
@@ -533,7 +538,7 @@ def main():
             h.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -32,10 +32,11 @@ def unpack_records(rec):
     return dict(pose=rec[:, :6].copy(), status=rec[:, 6].copy().view(np.int32), iters=rec[:, 7].copy().view(np.int32))
 
 
-def gather_records(local, world, dist=None):
-    """local: torch tensor (k, 8) of this rank's records for one step → (world, k, 8) on every rank"""
+def gather_records(local, world, dist=None, force=False):
+    """local: torch tensor (k, 8) of this rank's records for one step → (world, k, 8) on every rank
+    (force: issue the collective also for a world of one rank — the RCCL rehearsal of tests/test_gpu_rccl.py)"""
     import torch
-    if world == 1:
+    if world == 1 and not force:
         return local.unsqueeze(0)
     k = local.shape[0]
     out = torch.empty((world * k,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)   # concatenated along dim 0
