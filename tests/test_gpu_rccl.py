@@ -29,3 +29,50 @@ def test_bench_collectives_execute_over_rccl_with_one_rank(tmp_path):
     assert d["tracker"]["per_rank"] and len(d["tracker"]["per_rank"]) == 1            # the tracker-rate all_gather ran
     # the library that served the collectives announces itself (NCCL_DEBUG=VERSION prints "NCCL version … " / RCCL's banner)
     assert ("NCCL version" in r.stdout + r.stderr) or ("RCCL" in r.stdout + r.stderr), (r.stderr[-800:], r.stdout[-300:])
+
+
+@pytest.mark.gpu
+def test_native_multi_gpu_replay_one_process(tmp_path):
+    """host/replay_multi.cpp — SURVEY 8(e)'s single-process form: one handle per GPU, scan i -> GPU i mod N, ncclCommInitAll communicators,
+    one grouped ncclAllGather of the step's 32-byte pose records — built with hipcc against liblvi_hip.so and librccl and run with the GPUs
+    the box has (one: the one-rank form of the collective).  Its records equal, bit for bit, the ones a Python-driven handle returns."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    from helpers import small_params
+    pkg = graft.import_package()
+    hip = pkg.load_hip()
+    S = pkg.synth
+    kw = small_params(Horizon_SCAN=4096, max_raw_points=9000, max_map_points=400000, icp_max_iters=10)
+    g = pkg.LidarHotpath(hip, **kw)
+    mc, ms = S.make_map(g, 6, 8001, seed=4711)
+    n_raw, n_scans = 8001, 3
+    poses = [S.loop_pose(0.3 + 0.4 * k, 0.01, -0.01) for k in range(n_scans)]
+    scans = [S.make_scan(n_raw, poses[k], 200 + k) for k in range(n_scans)]
+    guesses = np.stack([S.perturbed_guess(poses[k], 3 + k) for k in range(n_scans)]).astype(np.float32)
+    g.map_set(mc, ms)
+    ref = []
+    for k in range(n_scans):
+        g.scan_upload(scans[k]); g.scan_organize(); g.scan_extract(); g.scan_downsample()
+        g.scan_match_async(guesses[k], 0)
+        ref.append(g.get_pose_record())
+    g.close()
+    hdir = os.path.dirname(pkg.HIP_LIB_PATH)
+    exe = tmp_path / "replay_multi"
+    src = os.path.join(pkg.PKG_DIR, "host", "replay_multi.cpp")
+    r = subprocess.run(["hipcc", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", str(exe), src, "-L" + hdir, "-llvi_hip", "-lrccl",
+                        "-Wl,-rpath," + hdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    np.concatenate(scans).tofile(tmp_path / "scans.bin"); mc.tofile(tmp_path / "mc.bin"); ms.tofile(tmp_path / "ms.bin"); guesses.tofile(tmp_path / "g.bin")
+    r = subprocess.run([str(exe), "8", "4096", str(tmp_path / "scans.bin"), str(n_scans), str(n_raw), str(tmp_path / "mc.bin"), str(len(mc)),
+                        str(tmp_path / "ms.bin"), str(len(ms)), str(tmp_path / "g.bin"), "10"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stderr[-2000:], r.stdout[-500:])
+    lines = r.stdout.strip().splitlines()
+    assert any(ln.startswith("backend hip") and " gpus 1 " in ln for ln in lines), lines[:4]        # (RCCL prints its version banner first)
+    recs = [ln.split() for ln in lines if ln.startswith("rec ")]
+    assert len(recs) == n_scans
+    for k, f in enumerate(recs):
+        assert int(f[1]) == k and int(f[2]) == ref[k]["status"] and int(f[3]) == ref[k]["iters"]
+        pose = np.array([float(v) for v in f[4:10]], np.float32)
+        np.testing.assert_array_equal(pose.view(np.uint32), ref[k]["pose"].view(np.uint32))
